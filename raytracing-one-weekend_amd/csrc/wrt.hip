@@ -1,0 +1,707 @@
+// libwrt.so: kernels and the C ABI (include/wrt.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wrt.h"
+#include "wrt_device.hpp"
+
+// ===========================================================================
+// kernels
+// ===========================================================================
+struct RenderArgs {
+    int width, height, s_begin, n_samples, max_bounces;
+    float t_min, t_max;
+    uint32_t k0, k1;
+    float* paths;                 // [width*height*n_samples][4]
+    unsigned long long* stats;    // wrt_stats layout
+    int tiles_x, tiles_y;
+    long long n_batches;          // 8x8-pixel tile x sample batches of 64 paths
+};
+
+static constexpr int RENDER_BLOCK = 256;
+static constexpr int STAT_PATHS = WRT_MAX_BOUNCES + 2;
+// paths[.].w = segments traced, plus this mark when the path was still alive
+// at the bounce limit (it then also counts as a ray entering bounce max_bounces)
+static constexpr int SURVIVOR_MARK = 100;
+
+// The bounce loop of main.render() (main.py:93-220) as one persistent kernel.
+// A wavefront owns a fixed, interleaved stream of 64-path batches (one 8x8
+// pixel tile at one sample index each).  Every lane carries one path; each
+// trip of the loop traces one segment for all live lanes, then lanes whose
+// path ended (miss, absorbed, bounce limit) are refilled from the stream, so
+// the wavefront stays full until its stream runs dry.
+__global__ __launch_bounds__(RENDER_BLOCK) void k_render(const SceneRec S, const RenderArgs A) {
+    const unsigned lane = threadIdx.x & 63u;
+    const long long wave = ((long long)blockIdx.x * RENDER_BLOCK + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * RENDER_BLOCK) >> 6;
+    // entries of this wave's stream: batches wave, wave + n_waves, ...
+    const long long my_batches = (A.n_batches > wave) ? (A.n_batches - wave + n_waves - 1) / n_waves : 0;
+    const long long stream_len = my_batches * 64;
+    long long cursor = 0;
+
+    bool live = false;
+    PathKey key;
+    key.k0 = A.k0; key.k1 = A.k1; key.x = key.y = key.s = 0;
+    int bounce = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    float cr = 1, cg = 1, cb = 1;
+    long long out_index = 0;
+    PairCounts pc = {0, 0, 0, 0};
+
+    while (true) {
+        // ---- refill dead lanes from the stream --------------------------
+        const unsigned long long dead = __ballot(!live);
+        if (dead != 0ull && cursor < stream_len) {
+            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+            const long long e = cursor + rank;
+            if (!live && e < stream_len) {
+                const long long batch = (e >> 6) * n_waves + wave;
+                const unsigned in_tile = (unsigned)(e & 63);
+                const long long tile = batch / A.n_samples;
+                const int s_local = (int)(batch - tile * A.n_samples);
+                const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+                const int x = tx * 8 + (int)(in_tile & 7u), y = ty * 8 + (int)(in_tile >> 3);
+                if (x < A.width && y < A.height) {
+                    key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)(A.s_begin + s_local);
+                    float o[3], d[3];
+                    camera_ray(*S.cam, A.width, A.height, key, o, d);
+                    ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+                    cr = cg = cb = 1.0f;
+                    bounce = 0;
+                    out_index = ((long long)x * A.height + y) * A.n_samples + s_local;
+                    live = true;
+                }
+            }
+            cursor += __popcll(dead);
+        }
+        if (live && A.max_bounces == 0) {
+            // bounce 0 is already the limit: the reference zeroes the path untraced (main.py:211-212)
+            f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
+            reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
+            live = false;
+        }
+        if (__ballot(live) == 0ull) {
+            if (cursor >= stream_len) break;
+            continue;
+        }
+        // ---- one segment for every live lane ------------------------------
+        Closest best;
+        closest_hit(S, 0, S.n_groups, live, ox, oy, oz, dx, dy, dz, A.t_min, A.t_max, best, pc);
+        if (live) {
+            bool done;
+            if (best.t < A.t_max) {
+                HitRecord h;
+                shade_record(S, best, ox, oy, oz, dx, dy, dz, h);
+                const MaterialRec& M = S.materials[h.material];
+                done = false;
+                if (M.kind != WRT_MAT_NONE) {
+                    Scattered sc;
+                    scatter_one(S, M, key, (uint32_t)bounce, dx, dy, dz, h, sc);
+                    ox = h.p[0]; oy = h.p[1]; oz = h.p[2];
+                    dx = sc.d[0]; dy = sc.d[1]; dz = sc.d[2];
+                    cr *= sc.col[0]; cg *= sc.col[1]; cb *= sc.col[2];
+                    done = sc.absorbed;
+                }
+            } else {
+                // sky, main.py:206-207
+                const float ts = (dy + 1.0f) * 0.5f;
+                cr *= (1.0f - ts) * S.horizon[0] + ts * S.zenith[0];
+                cg *= (1.0f - ts) * S.horizon[1] + ts * S.zenith[1];
+                cb *= (1.0f - ts) * S.horizon[2] + ts * S.zenith[2];
+                done = true;
+            }
+            ++bounce;
+            int mark = bounce;
+            if (!done && bounce == A.max_bounces) {   // still alive at the limit: main.py:212
+                cr = cg = cb = 0.0f;
+                mark += SURVIVOR_MARK;
+                done = true;
+            }
+            if (done) {
+                f32x4 rec = {cr, cg, cb, (float)mark};
+                reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
+                live = false;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (pc.sphere) atomicAdd(&A.stats[STAT_PATHS + 1], pc.sphere);
+        if (pc.triangle) atomicAdd(&A.stats[STAT_PATHS + 2], pc.triangle);
+        if (pc.cull) atomicAdd(&A.stats[STAT_PATHS + 3], pc.cull);
+        if (pc.disk) atomicAdd(&A.stats[STAT_PATHS + 4], pc.disk);
+    }
+}
+
+// Per pixel: sum the path colours over this launch's samples in sample order
+// (numpy.mean over the sample axis adds sequentially, main.py:219) and add the
+// sum to the accumulation image; histogram the segment counts.
+__global__ __launch_bounds__(256) void k_reduce_paths(const float* __restrict__ paths, float* __restrict__ accum,
+                                                      long long n_pixels, int n_samples, int max_bounces,
+                                                      unsigned long long* stats) {
+    __shared__ unsigned int hist[WRT_MAX_BOUNCES + 2];
+    for (int i = threadIdx.x; i < WRT_MAX_BOUNCES + 2; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < n_pixels; pix += stride) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(paths) + pix * n_samples;
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        for (int s = 0; s < n_samples; ++s) {
+            const f32x4 v = p[s];
+            r += v.x; g += v.y; b += v.z;
+            int entered = (int)v.w;                      // bounces entered = segments (+1 for survivors)
+            if (entered >= SURVIVOR_MARK) entered = entered - SURVIVOR_MARK + 1;
+            entered = entered < 0 ? 0 : (entered > max_bounces + 1 ? max_bounces + 1 : entered);
+            atomicAdd(&hist[entered], 1u);
+        }
+        accum[pix * 3 + 0] += r;
+        accum[pix * 3 + 1] += g;
+        accum[pix * 3 + 2] += b;
+    }
+    __syncthreads();
+    // stats[k] = paths that entered exactly k bounces (wrt_stats_read turns this into suffix sums)
+    for (int i = threadIdx.x; i <= max_bounces + 1; i += blockDim.x)
+        if (hist[i]) atomicAdd(&stats[i], (unsigned long long)hist[i]);
+}
+
+__global__ void k_finalize(const float* __restrict__ accum, long long n, float spp, float* __restrict__ image) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) image[i] = sqrtf(accum[i] / spp);
+}
+
+__global__ void k_generate_rays(const SceneRec S, int width, int height, int s_begin, int n_samples,
+                                uint32_t k0, uint32_t k1, float* __restrict__ origins, float* __restrict__ dirs) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)width * height * n_samples;
+    if (i >= n) return;
+    PathKey key;
+    key.k0 = k0; key.k1 = k1;
+    key.s = (uint32_t)(s_begin + (int)(i % n_samples));
+    const long long pix = i / n_samples;
+    key.y = (uint32_t)(pix % height);
+    key.x = (uint32_t)(pix / height);
+    float o[3], d[3];
+    camera_ray(*S.cam, width, height, key, o, d);
+    for (int a = 0; a < 3; ++a) { origins[i * 3 + a] = o[a]; dirs[i * 3 + a] = d[a]; }
+}
+
+struct IntersectOut {
+    uint8_t* hit; float* t; float* p; float* normal; float* uv; uint8_t* material; uint8_t* back;
+    int32_t* hit_group; int32_t* prim;
+};
+
+__global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, const float* __restrict__ origins,
+                                                   const float* __restrict__ dirs, long long n, float t_min,
+                                                   float t_max, IntersectOut O) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    if (live) {
+        ox = origins[i * 3]; oy = origins[i * 3 + 1]; oz = origins[i * 3 + 2];
+        dx = dirs[i * 3]; dy = dirs[i * 3 + 1]; dz = dirs[i * 3 + 2];
+    }
+    Closest best;
+    PairCounts pc = {0, 0, 0, 0};
+    const int g0 = group < 0 ? 0 : group, g1 = group < 0 ? S.n_groups : group + 1;
+    closest_hit(S, g0, g1, live, ox, oy, oz, dx, dy, dz, t_min, t_max, best, pc);
+    if (!live) return;
+    const bool hit = best.t < t_max;
+    HitRecord h;
+    for (int a = 0; a < 3; ++a) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
+    h.uv[0] = h.uv[1] = 0.0f; h.material = 255; h.back = false;
+    int prim = -1, grp = -1;
+    if (hit) {
+        shade_record(S, best, ox, oy, oz, dx, dy, dz, h);
+        grp = best.group;
+        prim = best.prim - S.groups[best.group].first;
+        if (S.groups[best.group].type == GROUP_DISK) prim = 0;
+    } else if (group >= 0 && S.groups[group].type != GROUP_SPHERES) {
+        h.material = S.groups[group].material;   // triangle_group.py:177, disk.py:86
+    }
+    if (O.hit) O.hit[i] = hit ? 1 : 0;
+    if (O.t) O.t[i] = hit ? best.t : (group < 0 ? 5001.0f : best.t);
+    if (O.p) for (int a = 0; a < 3; ++a) O.p[i * 3 + a] = h.p[a];
+    if (O.normal) for (int a = 0; a < 3; ++a) O.normal[i * 3 + a] = h.n[a];
+    if (O.uv) { O.uv[i * 2] = h.uv[0]; O.uv[i * 2 + 1] = h.uv[1]; }
+    if (O.material) O.material[i] = (uint8_t)h.material;
+    if (O.back) O.back[i] = h.back ? 1 : 0;
+    if (O.hit_group) O.hit_group[i] = grp;
+    if (O.prim) O.prim[i] = prim;
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const SceneRec S, int material_index, const float* __restrict__ dirs,
+                                                 const float* __restrict__ points, const float* __restrict__ normals,
+                                                 const float* __restrict__ uvs, const uint8_t* __restrict__ back,
+                                                 const int32_t* __restrict__ px, const int32_t* __restrict__ py,
+                                                 const int32_t* __restrict__ ps, int bounce, uint32_t k0, uint32_t k1,
+                                                 long long n, float* __restrict__ out_dirs,
+                                                 float* __restrict__ out_colours, uint8_t* __restrict__ absorbed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    HitRecord h;
+    for (int a = 0; a < 3; ++a) { h.p[a] = points[i * 3 + a]; h.n[a] = normals[i * 3 + a]; }
+    h.uv[0] = uvs[i * 2]; h.uv[1] = uvs[i * 2 + 1];
+    h.back = back[i] != 0;
+    h.material = material_index;
+    PathKey key;
+    key.k0 = k0; key.k1 = k1; key.x = (uint32_t)px[i]; key.y = (uint32_t)py[i]; key.s = (uint32_t)ps[i];
+    Scattered sc;
+    scatter_one(S, S.materials[material_index], key, (uint32_t)bounce, dirs[i * 3], dirs[i * 3 + 1],
+                dirs[i * 3 + 2], h, sc);
+    for (int a = 0; a < 3; ++a) { out_dirs[i * 3 + a] = sc.d[a]; out_colours[i * 3 + a] = sc.col[a]; }
+    absorbed[i] = sc.absorbed ? 1 : 0;
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct wrt_ctx {
+    int device = 0;
+    int cus = 0;
+    std::string err;
+    // host staging of the scene
+    std::vector<f32x4> h_sph;
+    std::vector<float> h_sph_radius;
+    std::vector<uint8_t> h_sph_material;
+    std::vector<f32x4> h_tri;
+    std::vector<f32x4> h_tri_shade;
+    std::vector<GroupRec> h_groups;
+    MaterialRec h_materials[WRT_MAX_MATERIALS];
+    float* d_textures[WRT_MAX_TEXTURES] = {nullptr};
+    TextureRec h_textures[WRT_MAX_TEXTURES];
+    CameraRec h_cam;
+    SceneRec scene;
+    bool committed = false;
+    // device copies
+    void* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    unsigned long long* d_stats = nullptr;
+    float* d_paths = nullptr;
+    size_t paths_bytes = 0;
+    int render_blocks = 0;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(wrt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, WRT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+static int bind(wrt_ctx* ctx) {
+    if (!ctx) return fail(nullptr, WRT_E_ARG, "null context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return WRT_OK;
+}
+
+template <typename T>
+static int fetch(wrt_ctx* ctx, std::vector<T>& dst, const T* src, size_t n) {
+    dst.resize(n);
+    if (n) HIP_TRY(ctx, hipMemcpy(dst.data(), src, n * sizeof(T), hipMemcpyDefault));
+    return WRT_OK;
+}
+
+static void reset_scene(wrt_ctx* ctx) {
+    ctx->h_sph.clear(); ctx->h_sph_radius.clear(); ctx->h_sph_material.clear();
+    ctx->h_tri.clear(); ctx->h_tri_shade.clear(); ctx->h_groups.clear();
+    std::memset(ctx->h_materials, 0, sizeof(ctx->h_materials));
+    std::memset(&ctx->scene, 0, sizeof(ctx->scene));
+    std::memset(&ctx->h_cam, 0, sizeof(ctx->h_cam));
+    ctx->scene.horizon[0] = ctx->scene.horizon[1] = ctx->scene.horizon[2] = 1.0f;
+    ctx->scene.zenith[0] = 0.5f; ctx->scene.zenith[1] = 0.7f; ctx->scene.zenith[2] = 1.0f;
+    ctx->committed = false;
+}
+
+extern "C" {
+
+int wrt_create(int device, wrt_ctx** out) {
+    if (!out) return fail(nullptr, WRT_E_ARG, "wrt_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return fail(nullptr, WRT_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, WRT_E_ARG, "wrt_create: no such device");
+    wrt_ctx* ctx = new wrt_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, WRT_E_HIP, std::string("device init: ") + hipGetErrorString(e));
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete ctx;
+        return fail(nullptr, WRT_E_STATE, std::string("libwrt is built for gfx950 only, device is ") + prop.gcnArchName);
+    }
+    ctx->cus = prop.multiProcessorCount;
+    if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(wrt_stats))) != hipSuccess ||
+        (e = hipMemset(ctx->d_stats, 0, sizeof(wrt_stats))) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, WRT_E_HIP, std::string("stats alloc: ") + hipGetErrorString(e));
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, RENDER_BLOCK, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    ctx->render_blocks = ctx->cus * per_cu;
+    std::memset(ctx->h_textures, 0, sizeof(ctx->h_textures));
+    reset_scene(ctx);
+    *out = ctx;
+    return WRT_OK;
+}
+
+int wrt_destroy(wrt_ctx* ctx) {
+    if (!ctx) return WRT_OK;
+    (void)hipSetDevice(ctx->device);
+    for (float*& t : ctx->d_textures) if (t) { (void)hipFree(t); t = nullptr; }
+    if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_paths) (void)hipFree(ctx->d_paths);
+    delete ctx;
+    return WRT_OK;
+}
+
+const char* wrt_last_error(const wrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int wrt_device_cus(const wrt_ctx* ctx) { return ctx ? ctx->cus : 0; }
+
+int wrt_scene_clear(wrt_ctx* ctx) {
+    if (int r = bind(ctx)) return r;
+    // textures stay allocated until replaced or the context is destroyed
+    reset_scene(ctx);
+    return WRT_OK;
+}
+
+static int new_group(wrt_ctx* ctx, const GroupRec& g, int* group_id) {
+    if (ctx->h_groups.size() >= (size_t)WRT_MAX_GROUPS) return fail(ctx, WRT_E_LIMIT, "too many groups");
+    ctx->h_groups.push_back(g);
+    ctx->committed = false;
+    if (group_id) *group_id = (int)ctx->h_groups.size() - 1;
+    return WRT_OK;
+}
+
+int wrt_add_sphere_group(wrt_ctx* ctx, const float* centres, const float* radii, const uint8_t* materials,
+                         int count, int* group_id) {
+    if (int r = bind(ctx)) return r;
+    if (!centres || !radii || !materials || count <= 0) return fail(ctx, WRT_E_ARG, "wrt_add_sphere_group: bad argument");
+    std::vector<float> c, rad;
+    std::vector<uint8_t> m;
+    if (int r = fetch(ctx, c, centres, (size_t)count * 3)) return r;
+    if (int r = fetch(ctx, rad, radii, (size_t)count)) return r;
+    if (int r = fetch(ctx, m, materials, (size_t)count)) return r;
+    GroupRec g;
+    std::memset(&g, 0, sizeof(g));
+    g.type = GROUP_SPHERES; g.first = (int)ctx->h_sph.size(); g.count = count; g.material = -1;
+    for (int i = 0; i < count; ++i) {
+        // radii**2 is a float32 product (sphere_group.py:165)
+        const float r2 = rad[i] * rad[i];
+        f32x4 s = {c[3 * i], c[3 * i + 1], c[3 * i + 2], r2};
+        ctx->h_sph.push_back(s);
+        ctx->h_sph_radius.push_back(rad[i]);
+        ctx->h_sph_material.push_back(m[i]);
+    }
+    return new_group(ctx, g, group_id);
+}
+
+int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const float* B, const float* n0,
+                           const float* n1, const float* n2, const float* uv0, const float* uv1, const float* uv2,
+                           int count, int material_id, const float bounds_centre[3], float bounds_radius,
+                           int* group_id) {
+    if (int r = bind(ctx)) return r;
+    if (!pt0 || !A || !B || !n0 || !n1 || !n2 || !uv0 || !uv1 || !uv2 || !bounds_centre || count <= 0)
+        return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: bad argument");
+    if (material_id < 0 || material_id >= WRT_MAX_MATERIALS)
+        return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: material index must fit uint8");
+    std::vector<float> v[9];
+    const float* src[9] = {pt0, A, B, n0, n1, n2, uv0, uv1, uv2};
+    for (int k = 0; k < 9; ++k)
+        if (int r = fetch(ctx, v[k], src[k], (size_t)count * (k < 6 ? 3 : 2))) return r;
+    GroupRec g;
+    std::memset(&g, 0, sizeof(g));
+    g.type = GROUP_TRIANGLES; g.first = (int)(ctx->h_tri.size() / 3); g.count = count; g.material = material_id;
+    g.c[0] = bounds_centre[0]; g.c[1] = bounds_centre[1]; g.c[2] = bounds_centre[2];
+    const float br2 = bounds_radius * bounds_radius;   // self.bounds_radius**2, float32
+    g.c[3] = br2;
+    for (int i = 0; i < count; ++i) {
+        const float* P = &v[0][3 * i]; const float* a = &v[1][3 * i]; const float* b = &v[2][3 * i];
+        f32x4 r0 = {P[0], P[1], P[2], a[0]}, r1 = {a[1], a[2], b[0], b[1]}, r2 = {b[2], 0.0f, 0.0f, 0.0f};
+        ctx->h_tri.push_back(r0); ctx->h_tri.push_back(r1); ctx->h_tri.push_back(r2);
+        const float* m0 = &v[3][3 * i]; const float* m1 = &v[4][3 * i]; const float* m2 = &v[5][3 * i];
+        const float* t0 = &v[6][2 * i]; const float* t1 = &v[7][2 * i]; const float* t2 = &v[8][2 * i];
+        f32x4 s0 = {m0[0], m0[1], m0[2], m1[0]}, s1 = {m1[1], m1[2], m2[0], m2[1]},
+              s2 = {m2[2], t0[0], t0[1], t1[0]}, s3 = {t1[1], t2[0], t2[1], 0.0f};
+        ctx->h_tri_shade.push_back(s0); ctx->h_tri_shade.push_back(s1);
+        ctx->h_tri_shade.push_back(s2); ctx->h_tri_shade.push_back(s3);
+    }
+    return new_group(ctx, g, group_id);
+}
+
+int wrt_add_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], const float U[3], const float V[3],
+                 double radius, int material_index, int* group_id) {
+    if (int r = bind(ctx)) return r;
+    if (!centre || !normal || !U || !V || !(radius > 0.0)) return fail(ctx, WRT_E_ARG, "wrt_add_disk: bad argument");
+    if (material_index < 0 || material_index >= WRT_MAX_MATERIALS)
+        return fail(ctx, WRT_E_ARG, "wrt_add_disk: material index must fit uint8");
+    GroupRec g;
+    std::memset(&g, 0, sizeof(g));
+    g.type = GROUP_DISK; g.first = 0; g.count = 1; g.material = material_index;
+    const float rf = (float)radius;               // float32 array / Python float (disk.py:79-80)
+    for (int a = 0; a < 3; ++a) {
+        g.c[a] = centre[a]; g.n[a] = normal[a];
+        const float ua = U[a] / rf, va = V[a] / rf;
+        g.u[a] = ua; g.v[a] = va;
+    }
+    g.c[3] = (float)(radius * radius);            // radius ** 2 as a Python float, compared in float32 (disk.py:27,69)
+    return new_group(ctx, g, group_id);
+}
+
+int wrt_set_materials(wrt_ctx* ctx, const wrt_material* table, int count) {
+    if (int r = bind(ctx)) return r;
+    if (!table || count < 0 || count > WRT_MAX_MATERIALS) return fail(ctx, WRT_E_ARG, "wrt_set_materials: bad argument");
+    std::memset(ctx->h_materials, 0, sizeof(ctx->h_materials));
+    for (int i = 0; i < count; ++i) {
+        const wrt_material& m = table[i];
+        if (m.kind < WRT_MAT_NONE || m.kind > WRT_MAT_DIELECTRIC) return fail(ctx, WRT_E_ARG, "unknown material kind");
+        if (m.kind == WRT_MAT_TEXTURED && (m.texture < 0 || m.texture >= WRT_MAX_TEXTURES))
+            return fail(ctx, WRT_E_ARG, "texture slot out of range");
+        MaterialRec& d = ctx->h_materials[i];
+        d.kind = m.kind; d.texture = m.texture;
+        for (int a = 0; a < 3; ++a) {
+            d.colour_a[a] = m.colour_a[a]; d.colour_b[a] = m.colour_b[a];
+            d.scale[a] = m.scale[a]; d.offset[a] = m.offset[a];
+        }
+        d.fuzz = (float)m.fuzziness;
+        d.fuzzy = m.fuzziness > 0.0001 ? 1 : 0;
+        d.ior = (float)m.ior;
+    }
+    ctx->committed = false;
+    return WRT_OK;
+}
+
+int wrt_set_texture(wrt_ctx* ctx, int slot, const float* rgb, int width, int height) {
+    if (int r = bind(ctx)) return r;
+    if (slot < 0 || slot >= WRT_MAX_TEXTURES || !rgb || width <= 0 || height <= 0)
+        return fail(ctx, WRT_E_ARG, "wrt_set_texture: bad argument");
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    if (ctx->d_textures[slot]) { HIP_TRY(ctx, hipFree(ctx->d_textures[slot])); ctx->d_textures[slot] = nullptr; }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_textures[slot], bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_textures[slot], rgb, bytes, hipMemcpyDefault));
+    TextureRec& t = ctx->h_textures[slot];
+    t.rgb = ctx->d_textures[slot]; t.w = width; t.h = height;
+    t.side_minus_one = (double)(float)(width < height ? width : height) - 1.0;
+    ctx->committed = false;
+    return WRT_OK;
+}
+
+int wrt_set_camera(wrt_ctx* ctx, const double pos[3], const double U[3], const double V[3],
+                   const double bottom_left[3], const double horiz[3], const double vert[3], double lens_radius) {
+    if (int r = bind(ctx)) return r;
+    if (!pos || !U || !V || !bottom_left || !horiz || !vert) return fail(ctx, WRT_E_ARG, "wrt_set_camera: null vector");
+    CameraRec& c = ctx->h_cam;
+    ctx->committed = false;
+    for (int a = 0; a < 3; ++a) {
+        c.pos[a] = pos[a]; c.U[a] = U[a]; c.V[a] = V[a];
+        c.bl[a] = bottom_left[a]; c.horiz[a] = horiz[a]; c.vert[a] = vert[a];
+    }
+    c.lens_radius = lens_radius;
+    return WRT_OK;
+}
+
+int wrt_set_sky(wrt_ctx* ctx, const float horizon[3], const float zenith[3]) {
+    if (int r = bind(ctx)) return r;
+    if (!horizon || !zenith) return fail(ctx, WRT_E_ARG, "wrt_set_sky: null vector");
+    for (int a = 0; a < 3; ++a) { ctx->scene.horizon[a] = horizon[a]; ctx->scene.zenith[a] = zenith[a]; }
+    return WRT_OK;
+}
+
+int wrt_scene_commit(wrt_ctx* ctx) {
+    if (int r = bind(ctx)) return r;
+    for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
+        if (ctx->h_materials[i].kind == WRT_MAT_TEXTURED && !ctx->h_textures[ctx->h_materials[i].texture].rgb)
+            return fail(ctx, WRT_E_STATE, "a textured material names a texture slot that was never set");
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_sph = up(ctx->h_sph.size() * sizeof(f32x4) + 16), b_rad = up(ctx->h_sph_radius.size() * 4 + 16),
+                 b_smat = up(ctx->h_sph_material.size() + 16), b_tri = up(ctx->h_tri.size() * sizeof(f32x4) + 16),
+                 b_shade = up(ctx->h_tri_shade.size() * sizeof(f32x4) + 16),
+                 b_grp = up(ctx->h_groups.size() * sizeof(GroupRec) + 16), b_mat = up(sizeof(ctx->h_materials)),
+                 b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam));
+    const size_t total = b_sph + b_rad + b_smat + b_tri + b_shade + b_grp + b_mat + b_tex + b_cam;
+    if (total > ctx->blob_bytes) {
+        if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
+        ctx->blob_bytes = total;
+    }
+    std::vector<unsigned char> host(total, 0);
+    size_t off = 0;
+    auto put = [&](const void* src, size_t bytes, size_t reserved) {
+        if (bytes) std::memcpy(host.data() + off, src, bytes);
+        unsigned char* dev = (unsigned char*)ctx->d_blob + off;
+        off += reserved;
+        return dev;
+    };
+    SceneRec& S = ctx->scene;
+    S.sph = (const f32x4*)put(ctx->h_sph.data(), ctx->h_sph.size() * sizeof(f32x4), b_sph);
+    S.sph_radius = (const float*)put(ctx->h_sph_radius.data(), ctx->h_sph_radius.size() * 4, b_rad);
+    S.sph_material = (const uint8_t*)put(ctx->h_sph_material.data(), ctx->h_sph_material.size(), b_smat);
+    S.tri = (const f32x4*)put(ctx->h_tri.data(), ctx->h_tri.size() * sizeof(f32x4), b_tri);
+    S.tri_shade = (const f32x4*)put(ctx->h_tri_shade.data(), ctx->h_tri_shade.size() * sizeof(f32x4), b_shade);
+    S.groups = (const GroupRec*)put(ctx->h_groups.data(), ctx->h_groups.size() * sizeof(GroupRec), b_grp);
+    S.materials = (const MaterialRec*)put(ctx->h_materials, sizeof(ctx->h_materials), b_mat);
+    S.textures = (const TextureRec*)put(ctx->h_textures, sizeof(ctx->h_textures), b_tex);
+    S.cam = (const CameraRec*)put(&ctx->h_cam, sizeof(ctx->h_cam), b_cam);
+    S.n_groups = (int)ctx->h_groups.size();
+    HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
+    ctx->committed = true;
+    return WRT_OK;
+}
+
+static int need_scene(wrt_ctx* ctx, const char* who) {
+    if (int r = bind(ctx)) return r;
+    if (!ctx->committed) return fail(ctx, WRT_E_STATE, std::string(who) + ": call wrt_scene_commit first");
+    return WRT_OK;
+}
+
+int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces, float t_min,
+               float t_max, uint64_t seed, float* accum, float* path_colours, void* stream) {
+    if (int r = need_scene(ctx, "wrt_render")) return r;
+    if (width <= 0 || height <= 0 || s_begin < 0 || s_end <= s_begin || !accum)
+        return fail(ctx, WRT_E_ARG, "wrt_render: bad size or null accum");
+    if (max_bounces < 0 || max_bounces > WRT_MAX_BOUNCES)
+        return fail(ctx, WRT_E_LIMIT, "wrt_render: max_bounces must be in [0, 62]");
+    if (width > 65535 * 8 || height > 65535 * 8) return fail(ctx, WRT_E_LIMIT, "wrt_render: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_pixels = (long long)width * height;
+    const int n_total = s_end - s_begin;
+    // samples per launch: bounded by the path workspace (16 bytes per path)
+    int per_launch = n_total;
+    if (!path_colours) {
+        const long long budget_paths = (2ll << 30) / 16;      // 2 GiB workspace
+        long long fit = budget_paths / n_pixels;
+        if (fit < 1) fit = 1;
+        if (per_launch > fit) per_launch = (int)fit;
+        const size_t need = (size_t)n_pixels * per_launch * 16;
+        if (need > ctx->paths_bytes) {
+            if (ctx->d_paths) { HIP_TRY(ctx, hipFree(ctx->d_paths)); ctx->d_paths = nullptr; ctx->paths_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_paths, need));
+            ctx->paths_bytes = need;
+        }
+    }
+    for (int s0 = 0; s0 < n_total; s0 += per_launch) {
+        const int ns = (n_total - s0 < per_launch) ? n_total - s0 : per_launch;
+        RenderArgs A;
+        A.width = width; A.height = height; A.s_begin = s_begin + s0; A.n_samples = ns; A.max_bounces = max_bounces;
+        A.t_min = t_min; A.t_max = t_max;
+        A.k0 = (uint32_t)(seed & 0xffffffffu); A.k1 = (uint32_t)(seed >> 32);
+        A.paths = path_colours ? path_colours : ctx->d_paths;
+        A.stats = ctx->d_stats;
+        A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
+        A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
+        long long waves_wanted = A.n_batches;
+        int blocks = ctx->render_blocks;
+        const long long blocks_wanted = (waves_wanted + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
+        if (blocks_wanted < blocks) blocks = (int)blocks_wanted;
+        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, ctx->scene, A);
+        HIP_TRY(ctx, hipGetLastError());
+        const int rblocks = (int)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_reduce_paths, dim3(rblocks), dim3(256), 0, st, A.paths, accum, n_pixels, ns,
+                           max_bounces, ctx->d_stats);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return WRT_OK;
+}
+
+int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total, float* image, void* stream) {
+    if (int r = bind(ctx)) return r;
+    if (!accum || !image || n_values <= 0 || spp_total <= 0) return fail(ctx, WRT_E_ARG, "wrt_finalize: bad argument");
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream, accum,
+                       (long long)n_values, (float)spp_total, image);
+    HIP_TRY(ctx, hipGetLastError());
+    return WRT_OK;
+}
+
+int wrt_stats_reset(wrt_ctx* ctx, void* stream) {
+    if (int r = bind(ctx)) return r;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(wrt_stats), (hipStream_t)stream));
+    return WRT_OK;
+}
+
+int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
+    if (int r = bind(ctx)) return r;
+    if (!out) return fail(ctx, WRT_E_ARG, "wrt_stats_read: out is null");
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long raw[sizeof(wrt_stats) / 8];
+    HIP_TRY(ctx, hipMemcpy(raw, ctx->d_stats, sizeof(wrt_stats), hipMemcpyDeviceToHost));
+    // raw[k], k <= 63: paths that entered exactly k bounces
+    std::memset(out, 0, sizeof(*out));
+    unsigned long long paths = 0;
+    for (int k = 0; k < STAT_PATHS; ++k) paths += raw[k];
+    unsigned long long more = paths;            // paths that entered more than b bounces
+    for (int b = 0; b < STAT_PATHS; ++b) {
+        more -= raw[b];
+        out->rays_per_bounce[b] = more;
+    }
+    out->paths = paths;
+    out->sphere_pairs = raw[STAT_PATHS + 1];
+    out->triangle_pairs = raw[STAT_PATHS + 2];
+    out->cull_tests = raw[STAT_PATHS + 3];
+    out->disk_pairs = raw[STAT_PATHS + 4];
+    return WRT_OK;
+}
+
+int wrt_generate_rays(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, uint64_t seed, float* origins,
+                      float* dirs, void* stream) {
+    if (int r = bind(ctx)) return r;
+    if (width <= 0 || height <= 0 || s_begin < 0 || s_end <= s_begin || !origins || !dirs)
+        return fail(ctx, WRT_E_ARG, "wrt_generate_rays: bad argument");
+    const long long n = (long long)width * height * (s_end - s_begin);
+    hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->scene, width, height, s_begin, s_end - s_begin, (uint32_t)(seed & 0xffffffffu),
+                       (uint32_t)(seed >> 32), origins, dirs);
+    HIP_TRY(ctx, hipGetLastError());
+    return WRT_OK;
+}
+
+int wrt_intersect(wrt_ctx* ctx, int group, const float* origins, const float* dirs, int64_t n, float t_min,
+                  float t_max, uint8_t* hit, float* t, float* p, float* normal, float* uv, uint8_t* material,
+                  uint8_t* back, int32_t* hit_group, int32_t* prim, void* stream) {
+    if (int r = need_scene(ctx, "wrt_intersect")) return r;
+    if (!origins || !dirs || n < 0) return fail(ctx, WRT_E_ARG, "wrt_intersect: bad argument");
+    if (group < -1 || group >= ctx->scene.n_groups) return fail(ctx, WRT_E_ARG, "wrt_intersect: no such group");
+    if (n == 0) return WRT_OK;
+    IntersectOut O = {hit, t, p, normal, uv, material, back, hit_group, prim};
+    hipLaunchKernelGGL(k_intersect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
+                       group, origins, dirs, (long long)n, t_min, t_max, O);
+    HIP_TRY(ctx, hipGetLastError());
+    return WRT_OK;
+}
+
+int wrt_scatter(wrt_ctx* ctx, int material_index, const float* dirs, const float* points, const float* normals,
+                const float* uvs, const uint8_t* back, const int32_t* px, const int32_t* py, const int32_t* ps,
+                int bounce, uint64_t seed, int64_t n, float* out_dirs, float* out_colours, uint8_t* absorbed,
+                void* stream) {
+    if (int r = need_scene(ctx, "wrt_scatter")) return r;
+    if (material_index < 0 || material_index >= WRT_MAX_MATERIALS ||
+        ctx->h_materials[material_index].kind == WRT_MAT_NONE)
+        return fail(ctx, WRT_E_ARG, "wrt_scatter: no such material");
+    if (!dirs || !points || !normals || !uvs || !back || !px || !py || !ps || !out_dirs || !out_colours || !absorbed ||
+        n < 0 || bounce < 0 || bounce > 255)
+        return fail(ctx, WRT_E_ARG, "wrt_scatter: bad argument");
+    if (n == 0) return WRT_OK;
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
+                       material_index, dirs, points, normals, uvs, back, px, py, ps, bounce,
+                       (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (long long)n, out_dirs, out_colours,
+                       absorbed);
+    HIP_TRY(ctx, hipGetLastError());
+    return WRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,333 @@
+"""
+ctypes binding of libwrt.so (C ABI: include/wrt.h) and the device-buffer
+plumbing.  PyTorch-ROCm tensors are used only as device memory and streams.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible, every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libwrt.so")
+
+MAX_BOUNCES = 62
+MAX_MATERIALS = 256
+MAX_TEXTURES = 16
+SURVIVOR_MARK = 100
+
+(MAT_NONE, MAT_DIFFUSE, MAT_TEXTURED, MAT_CHECKER, MAT_NORMAL_RGB, MAT_NORMAL_DISCRETE, MAT_METAL,
+ MAT_DIELECTRIC) = range(8)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class WrtMaterial(ctypes.Structure):
+    _fields_ = [
+        ("kind", ctypes.c_int32), ("texture", ctypes.c_int32),
+        ("colour_a", ctypes.c_float * 3), ("colour_b", ctypes.c_float * 3),
+        ("scale", ctypes.c_double * 3), ("offset", ctypes.c_double * 3),
+        ("fuzziness", ctypes.c_double), ("ior", ctypes.c_double),
+    ]
+
+
+class WrtStats(ctypes.Structure):
+    _fields_ = [
+        ("rays_per_bounce", ctypes.c_uint64 * (MAX_BOUNCES + 2)),
+        ("paths", ctypes.c_uint64), ("sphere_pairs", ctypes.c_uint64), ("triangle_pairs", ctypes.c_uint64),
+        ("cull_tests", ctypes.c_uint64), ("disk_pairs", ctypes.c_uint64),
+    ]
+
+
+_vp, _i, _f, _d, _u64, _i64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_uint64,
+                               ctypes.c_int64)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> argument types; every symbol include/wrt.h declares
+SIGNATURES = {
+    "wrt_create": [_i, ctypes.POINTER(_vp)],
+    "wrt_destroy": [_vp],
+    "wrt_last_error": [_vp],
+    "wrt_device_cus": [_vp],
+    "wrt_scene_clear": [_vp],
+    "wrt_add_sphere_group": [_vp, _vp, _vp, _vp, _i, _ip],
+    "wrt_add_triangle_group": [_vp] + [_vp] * 9 + [_i, _i, _vp, _f, _ip],
+    "wrt_add_disk": [_vp, _vp, _vp, _vp, _vp, _d, _i, _ip],
+    "wrt_set_materials": [_vp, ctypes.POINTER(WrtMaterial), _i],
+    "wrt_set_texture": [_vp, _i, _vp, _i, _i],
+    "wrt_set_camera": [_vp] + [_vp] * 6 + [_d],
+    "wrt_set_sky": [_vp, _vp, _vp],
+    "wrt_scene_commit": [_vp],
+    "wrt_render": [_vp, _i, _i, _i, _i, _i, _f, _f, _u64, _vp, _vp, _vp],
+    "wrt_finalize": [_vp, _vp, _i64, _i, _vp, _vp],
+    "wrt_stats_reset": [_vp, _vp],
+    "wrt_stats_read": [_vp, ctypes.POINTER(WrtStats), _vp],
+    "wrt_generate_rays": [_vp, _i, _i, _i, _i, _u64, _vp, _vp, _vp],
+    "wrt_intersect": [_vp, _i, _vp, _vp, _i64, _f, _f] + [_vp] * 9 + [_vp],
+    "wrt_scatter": [_vp, _i] + [_vp] * 8 + [_i, _u64, _i64, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libwrt.so and declare every entry point (no GPU needed)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                              f"g.build()'` (hipcc --offload-arch=gfx950)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "wrt_last_error" else ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise NativeError("weekend_raytracer needs a ROCm GPU (MI355X); there is no CPU fallback")
+    return torch
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.single)
+
+
+def _hostptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class Context:
+    """One wrt_ctx on one GPU, plus torch-side helpers."""
+
+    def __init__(self, device=None):
+        torch = _torch()
+        self.lib = load_library()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        handle = ctypes.c_void_p()
+        rc = self.lib.wrt_create(self.device, ctypes.byref(handle))
+        if rc != 0:
+            raise NativeError(f"wrt_create: {self.lib.wrt_last_error(None).decode()}")
+        self.handle = handle
+        self.scene_token = None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.wrt_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what} failed ({rc}): {self.lib.wrt_last_error(self.handle).decode()}")
+
+    def stream(self):
+        torch = _torch()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.torch_device).cuda_stream)
+
+    @property
+    def compute_units(self):
+        return self.lib.wrt_device_cus(self.handle)
+
+    # ---- scene ---------------------------------------------------------
+    def upload(self, flat):
+        """Upload a flat scene (camera / groups / materials / sky dictionaries;
+        any part may be absent)."""
+        lib, h = self.lib, self.handle
+        self.check(lib.wrt_scene_clear(h), "wrt_scene_clear")
+        gid = ctypes.c_int()
+        for g in flat.get("groups", []):
+            if g["type"] == "spheres":
+                c, r = _f32(g["centres"]), _f32(g["radii"])
+                m = np.ascontiguousarray(g["materials"], dtype=np.ubyte)
+                self.check(lib.wrt_add_sphere_group(h, _hostptr(c), _hostptr(r), _hostptr(m), r.shape[0],
+                                                    ctypes.byref(gid)), "wrt_add_sphere_group")
+            elif g["type"] == "triangles":
+                arrs = [_f32(g[k]) for k in ("pt0", "A", "B", "n0", "n1", "n2", "uv0", "uv1", "uv2")]
+                bc = _f32(g["bounds_centre"])
+                self.check(lib.wrt_add_triangle_group(h, *[_hostptr(a) for a in arrs], arrs[0].shape[0],
+                                                      int(g["material_id"]), _hostptr(bc),
+                                                      float(np.single(g["bounds_radius"])), ctypes.byref(gid)),
+                           "wrt_add_triangle_group")
+            elif g["type"] == "disk":
+                vecs = [_f32(g[k]) for k in ("centre", "normal", "U", "V")]
+                self.check(lib.wrt_add_disk(h, *[_hostptr(a) for a in vecs], float(g["radius"]),
+                                            int(g["material_index"]), ctypes.byref(gid)), "wrt_add_disk")
+            else:
+                raise ValueError(g["type"])
+        mats = flat.get("materials", {})
+        if mats:
+            count = max(mats) + 1
+            if min(mats) < 0 or count > MAX_MATERIALS:
+                raise ValueError("material indices must fit the reference's uint8 (0..255)")
+            table = (WrtMaterial * count)()
+            slot = 0
+            for index, m in mats.items():
+                e = table[index]
+                kind = m["kind"]
+                if kind == "diffuse":
+                    e.kind = MAT_DIFFUSE
+                    e.colour_a[:] = [float(v) for v in _f32(m["colour"])]
+                elif kind == "textured":
+                    if slot >= MAX_TEXTURES:
+                        raise ValueError("too many textures")
+                    px = _f32(m["pixels"])
+                    self.check(lib.wrt_set_texture(h, slot, _hostptr(px), px.shape[1], px.shape[0]),
+                               "wrt_set_texture")
+                    e.kind, e.texture = MAT_TEXTURED, slot
+                    slot += 1
+                elif kind == "checker":
+                    e.kind = MAT_CHECKER
+                    e.colour_a[:] = [float(v) for v in _f32(m["colour_a"])]
+                    e.colour_b[:] = [float(v) for v in _f32(m["colour_b"])]
+                    e.scale[:] = [float(v) for v in np.asarray(m["scale"], dtype=np.double)]
+                    e.offset[:] = [float(v) for v in np.asarray(m["offset"], dtype=np.double)]
+                elif kind == "normal_rgb":
+                    e.kind = MAT_NORMAL_RGB
+                elif kind == "normal_discrete":
+                    e.kind = MAT_NORMAL_DISCRETE
+                elif kind == "metal":
+                    e.kind = MAT_METAL
+                    e.colour_a[:] = [float(v) for v in _f32(m["colour"])]
+                    e.fuzziness = float(m["fuzziness"])
+                elif kind == "dielectric":
+                    e.kind = MAT_DIELECTRIC
+                    e.ior = float(m["ior"])
+                else:
+                    raise ValueError(kind)
+            self.check(lib.wrt_set_materials(h, table, count), "wrt_set_materials")
+        cam = flat.get("camera")
+        if cam is not None:
+            v = [np.ascontiguousarray(cam[k], dtype=np.double) for k in ("pos", "U", "V", "bottom_left", "horiz",
+                                                                         "vert")]
+            self.check(lib.wrt_set_camera(h, *[_hostptr(a) for a in v], float(cam["lens_radius"])),
+                       "wrt_set_camera")
+        sky = flat.get("sky")
+        if sky is not None:
+            a, b = _f32(sky["horizon"]), _f32(sky["zenith"])
+            self.check(lib.wrt_set_sky(h, _hostptr(a), _hostptr(b)), "wrt_set_sky")
+        self.check(lib.wrt_scene_commit(h), "wrt_scene_commit")
+        self.scene_token = None
+
+    # ---- device helpers ------------------------------------------------
+    def to_device(self, a, dtype):
+        torch = _torch()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.torch_device)
+
+    def empty(self, shape, dtype):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype, device=self.torch_device)
+
+    def zeros(self, shape, dtype):
+        torch = _torch()
+        return torch.zeros(shape, dtype=dtype, device=self.torch_device)
+
+    # ---- entry points ----------------------------------------------------
+    def generate_rays(self, width, height, s_begin, s_end, seed):
+        torch = _torch()
+        n = width * height * (s_end - s_begin)
+        o = self.empty((n, 3), torch.float32)
+        d = self.empty((n, 3), torch.float32)
+        self.check(self.lib.wrt_generate_rays(self.handle, width, height, s_begin, s_end, seed, _dptr(o), _dptr(d),
+                                              self.stream()), "wrt_generate_rays")
+        return o, d
+
+    def intersect(self, group, origins, dirs, t_min, t_max):
+        """origins, dirs: numpy (n,3).  -> dict of numpy arrays."""
+        torch = _torch()
+        o = self.to_device(origins, np.single)
+        d = self.to_device(dirs, np.single)
+        n = o.shape[0]
+        out = dict(hit=self.empty((n,), torch.uint8), t=self.empty((n,), torch.float32),
+                   p=self.empty((n, 3), torch.float32), n=self.empty((n, 3), torch.float32),
+                   uv=self.empty((n, 2), torch.float32), mat=self.empty((n,), torch.uint8),
+                   back=self.empty((n,), torch.uint8), group=self.empty((n,), torch.int32),
+                   prim=self.empty((n,), torch.int32))
+        self.check(self.lib.wrt_intersect(self.handle, group, _dptr(o), _dptr(d), n, t_min, t_max,
+                                          *[_dptr(out[k]) for k in ("hit", "t", "p", "n", "uv", "mat", "back",
+                                                                    "group", "prim")], self.stream()),
+                   "wrt_intersect")
+        res = {k: v.cpu().numpy() for k, v in out.items()}
+        res["hit"] = res["hit"].astype(bool)
+        res["back"] = res["back"].astype(bool)
+        return res
+
+    def scatter(self, material_index, dirs, points, normals, uvs, back, px, py, ps, bounce, seed):
+        torch = _torch()
+        n = np.asarray(dirs).shape[0]
+        ins = [self.to_device(a, np.single) for a in (dirs, points, normals, uvs)]
+        b = self.to_device(np.asarray(back, dtype=bool).astype(np.ubyte), np.ubyte)
+        ids = [self.to_device(np.broadcast_to(np.asarray(a), (n,)), np.int32) for a in (px, py, ps)]
+        od, oc = self.empty((n, 3), torch.float32), self.empty((n, 3), torch.float32)
+        ab = self.empty((n,), torch.uint8)
+        self.check(self.lib.wrt_scatter(self.handle, material_index, *[_dptr(t) for t in ins], _dptr(b),
+                                        *[_dptr(t) for t in ids], int(bounce), int(seed), n, _dptr(od), _dptr(oc),
+                                        _dptr(ab), self.stream()), "wrt_scatter")
+        return od.cpu().numpy(), oc.cpu().numpy(), ab.cpu().numpy().astype(bool)
+
+    def render(self, width, height, s_begin, s_end, max_bounces, seed, accum, t_min=0.001, t_max=1000.0,
+               paths=None):
+        """Asynchronous on the current torch stream.  accum: float32 CUDA
+        tensor (width, height, 3), added to.  paths: optional float32 CUDA
+        tensor (width*height*(s_end-s_begin), 4)."""
+        self.check(self.lib.wrt_render(self.handle, width, height, s_begin, s_end, max_bounces, t_min, t_max,
+                                       int(seed), _dptr(accum), _dptr(paths), self.stream()), "wrt_render")
+
+    def finalize(self, accum, spp_total):
+        image = self.empty(tuple(accum.shape), accum.dtype)
+        self.check(self.lib.wrt_finalize(self.handle, _dptr(accum), accum.numel(), int(spp_total), _dptr(image),
+                                         self.stream()), "wrt_finalize")
+        return image
+
+    def stats_reset(self):
+        self.check(self.lib.wrt_stats_reset(self.handle, self.stream()), "wrt_stats_reset")
+
+    def stats(self):
+        s = WrtStats()
+        self.check(self.lib.wrt_stats_read(self.handle, ctypes.byref(s), self.stream()), "wrt_stats_read")
+        return dict(rays_per_bounce=np.array(list(s.rays_per_bounce), dtype=np.int64), paths=int(s.paths),
+                    sphere_pairs=int(s.sphere_pairs), triangle_pairs=int(s.triangle_pairs),
+                    cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs))
+
+
+_contexts = {}
+
+
+def context(device=None):
+    """The shared context of a GPU (created on first use)."""
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device()
+    device = int(device)
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+def use_scene(ctx, owner, flat_fn):
+    """Upload owner's flat scene into ctx unless it is already there."""
+    token = (id(owner), getattr(owner, "_version", 0))
+    if ctx.scene_token != token:
+        ctx.upload(flat_fn())
+        ctx._scene_owner = owner           # keeps id(owner) unique while the token is live
+        ctx.scene_token = token

@@ -17,9 +17,8 @@ def load_texture(name):
     img = Image.open(os.path.join(ASSETS, name))
     if img.mode not in ("RGB", "RGBA"):
         raise Exception(f"Unsupported texture image mode: {img.mode}")
-    px = np.array(img.getdata(), dtype=np.single)
-    px /= 255.0
-    px = px.reshape((img.height, img.width, len(img.mode)))[:, :, 0:3]
+    px = np.asarray(img, dtype=np.single).reshape((img.height, img.width, len(img.mode)))
+    px = (px / np.single(255.0))[:, :, 0:3]
     return np.ascontiguousarray(np.flipud(px))
 
 
