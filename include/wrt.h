@@ -152,6 +152,14 @@ int wrt_stats_reset(wrt_ctx* ctx, void* stream);
 /* synchronises `stream`, then copies the statistics out */
 int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream);
 
+/* Measurement aid (the reference times render() with perf_counter, main.py:93,229):
+   while enabled, every launch of the bounce kernel inside wrt_render is
+   bracketed by HIP events on the launch stream; wrt_profile_read waits for
+   them, returns the summed kernel time and launch count since the last read,
+   and clears them. */
+int wrt_profile_enable(wrt_ctx* ctx, int on);
+int wrt_profile_read(wrt_ctx* ctx, double* kernel_ms, int* launches);
+
 /* ---- stage entry points (same device code as wrt_render) ---------------- */
 /* Camera.get_ray_components (camera.py:108-190): origins, dirs: device
    pointers [width*height*(s_end-s_begin)][3] float32 in ray-id order */

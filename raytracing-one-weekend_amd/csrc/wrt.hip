@@ -283,6 +283,9 @@ struct wrt_ctx {
     float* d_paths = nullptr;
     size_t paths_bytes = 0;
     int render_blocks = 0;
+    // optional timing of the bounce kernel alone (wrt_profile_*)
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
 };
 
 static thread_local std::string g_create_error;
@@ -366,6 +369,7 @@ int wrt_destroy(wrt_ctx* ctx) {
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_paths) (void)hipFree(ctx->d_paths);
+    for (auto& pr : ctx->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete ctx;
     return WRT_OK;
 }
@@ -609,8 +613,18 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
         int blocks = ctx->render_blocks;
         const long long blocks_wanted = (waves_wanted + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
         if (blocks_wanted < blocks) blocks = (int)blocks_wanted;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (ctx->profiling) {
+            HIP_TRY(ctx, hipEventCreate(&ev0));
+            HIP_TRY(ctx, hipEventCreate(&ev1));
+            HIP_TRY(ctx, hipEventRecord(ev0, st));
+        }
         hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, ctx->scene, A);
         HIP_TRY(ctx, hipGetLastError());
+        if (ctx->profiling) {
+            HIP_TRY(ctx, hipEventRecord(ev1, st));
+            ctx->timed.emplace_back(ev0, ev1);
+        }
         const int rblocks = (int)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
         hipLaunchKernelGGL(k_reduce_paths, dim3(rblocks), dim3(256), 0, st, A.paths, accum, n_pixels, ns,
                            max_bounces, ctx->d_stats);
@@ -625,6 +639,30 @@ int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_tot
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream, accum,
                        (long long)n_values, (float)spp_total, image);
     HIP_TRY(ctx, hipGetLastError());
+    return WRT_OK;
+}
+
+int wrt_profile_enable(wrt_ctx* ctx, int on) {
+    if (int r = bind(ctx)) return r;
+    ctx->profiling = on != 0;
+    return WRT_OK;
+}
+
+int wrt_profile_read(wrt_ctx* ctx, double* kernel_ms, int* launches) {
+    if (int r = bind(ctx)) return r;
+    if (!kernel_ms || !launches) return fail(ctx, WRT_E_ARG, "wrt_profile_read: null output");
+    double total = 0.0;
+    for (auto& pr : ctx->timed) {
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        total += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    *kernel_ms = total;
+    *launches = (int)ctx->timed.size();
+    ctx->timed.clear();
     return WRT_OK;
 }
 
@@ -674,9 +712,9 @@ int wrt_intersect(wrt_ctx* ctx, int group, const float* origins, const float* di
                   float t_max, uint8_t* hit, float* t, float* p, float* normal, float* uv, uint8_t* material,
                   uint8_t* back, int32_t* hit_group, int32_t* prim, void* stream) {
     if (int r = need_scene(ctx, "wrt_intersect")) return r;
-    if (!origins || !dirs || n < 0) return fail(ctx, WRT_E_ARG, "wrt_intersect: bad argument");
     if (group < -1 || group >= ctx->scene.n_groups) return fail(ctx, WRT_E_ARG, "wrt_intersect: no such group");
     if (n == 0) return WRT_OK;
+    if (!origins || !dirs || n < 0) return fail(ctx, WRT_E_ARG, "wrt_intersect: bad argument");
     IntersectOut O = {hit, t, p, normal, uv, material, back, hit_group, prim};
     hipLaunchKernelGGL(k_intersect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
                        group, origins, dirs, (long long)n, t_min, t_max, O);
@@ -692,10 +730,10 @@ int wrt_scatter(wrt_ctx* ctx, int material_index, const float* dirs, const float
     if (material_index < 0 || material_index >= WRT_MAX_MATERIALS ||
         ctx->h_materials[material_index].kind == WRT_MAT_NONE)
         return fail(ctx, WRT_E_ARG, "wrt_scatter: no such material");
+    if (n == 0) return WRT_OK;
     if (!dirs || !points || !normals || !uvs || !back || !px || !py || !ps || !out_dirs || !out_colours || !absorbed ||
         n < 0 || bounce < 0 || bounce > 255)
         return fail(ctx, WRT_E_ARG, "wrt_scatter: bad argument");
-    if (n == 0) return WRT_OK;
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
                        material_index, dirs, points, normals, uvs, back, px, py, ps, bounce,
                        (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (long long)n, out_dirs, out_colours,

@@ -64,6 +64,8 @@ SIGNATURES = {
     "wrt_scene_commit": [_vp],
     "wrt_render": [_vp, _i, _i, _i, _i, _i, _f, _f, _u64, _vp, _vp, _vp],
     "wrt_finalize": [_vp, _vp, _i64, _i, _vp, _vp],
+    "wrt_profile_enable": [_vp, _i],
+    "wrt_profile_read": [_vp, ctypes.POINTER(ctypes.c_double), _ip],
     "wrt_stats_reset": [_vp, _vp],
     "wrt_stats_read": [_vp, ctypes.POINTER(WrtStats), _vp],
     "wrt_generate_rays": [_vp, _i, _i, _i, _i, _u64, _vp, _vp, _vp],
@@ -298,6 +300,15 @@ class Context:
         self.check(self.lib.wrt_finalize(self.handle, _dptr(accum), accum.numel(), int(spp_total), _dptr(image),
                                          self.stream()), "wrt_finalize")
         return image
+
+    def profile(self, on):
+        self.check(self.lib.wrt_profile_enable(self.handle, 1 if on else 0), "wrt_profile_enable")
+
+    def profile_read(self):
+        """-> (summed bounce-kernel milliseconds, launches) since the last read."""
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        self.check(self.lib.wrt_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n)), "wrt_profile_read")
+        return ms.value, n.value
 
     def stats_reset(self):
         self.check(self.lib.wrt_stats_reset(self.handle, self.stream()), "wrt_stats_reset")

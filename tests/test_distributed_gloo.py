@@ -1,0 +1,59 @@
+"""
+The multi-GPU path on CPU: two gloo ranks shard the samples, render their
+shard (the CPU oracle stands in for the GPU renderer), all-reduce the
+accumulation images and must reproduce the single-process image.
+"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import numpy_path
+from tests import helpers
+from weekend_raytracer import distributed
+
+
+def test_shard_samples_partition():
+    for total in (0, 1, 7, 100, 1024):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_samples(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = helpers.golden("frame_demo")
+    scene = helpers.golden_scene(f)
+    w, h, s, b, _ = (int(v) for v in f["size"])
+    w, h = 24, 14                                   # keep the CPU suite short
+    seed = int(f["seed"])
+
+    def render_samples(s_begin, s_end):
+        r = numpy_path.render(scene, w, h, s_end - s_begin, b, seed, s_begin=s_begin)
+        return torch.from_numpy(np.ascontiguousarray(r["sample_sum"]))
+
+    accum = distributed.accumulate_sharded(render_samples, s, rank, world, lambda t: dist.all_reduce(t))
+    np.save(os.path.join(out_dir, f"accum{rank}.npy"), accum.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sample_sharding_matches_single_process(tmp_path):
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a0, a1 = (np.load(tmp_path / f"accum{r}.npy") for r in range(2))
+    assert np.array_equal(a0, a1)                   # every rank holds the full sum
+    f = helpers.golden("frame_demo")
+    scene = helpers.golden_scene(f)
+    s, b = int(f["size"][2]), int(f["size"][3])
+    whole = numpy_path.render(scene, 24, 14, s, b, int(f["seed"]))
+    # identical samples, float32 additions associated differently
+    assert np.allclose(a0, whole["sample_sum"], rtol=1e-6, atol=1e-6)
