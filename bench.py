@@ -201,6 +201,11 @@ def main():
                 "pairs_per_launch": {"triangle": stats["triangle_pairs"] // max(1, launches),
                                      "sphere": stats["sphere_pairs"] // max(1, launches),
                                      "cull": stats["cull_tests"] // max(1, launches)},
+                "lane_efficiency": {
+                    "triangle_loops": round(stats["triangle_pairs"] / stats["triangle_lane_slots"], 4)
+                    if stats["triangle_lane_slots"] else None,
+                    "sphere_loops": round(stats["sphere_pairs"] / stats["sphere_lane_slots"], 4)
+                    if stats["sphere_lane_slots"] else None},
                 "note": "FP32 vector (VALU) roofline: this path is not a dense contraction, MFMA is not used; "
                         "flops = 45/ray-triangle pair + 19/ray-sphere pair + 14/cull test as the reference "
                         "evaluates them",

@@ -80,6 +80,10 @@ typedef struct wrt_stats {
     uint64_t triangle_pairs;   /* (ray, triangle) pairs after the bounding-sphere cull */
     uint64_t cull_tests;       /* (ray, triangle group) bounding-sphere tests */
     uint64_t disk_pairs;
+    /* lane slots spent in the wave-uniform group loops (64 x primitives per run);
+       pairs evaluated there / slots = lane efficiency of the dominant loops */
+    uint64_t sphere_lane_slots;
+    uint64_t triangle_lane_slots;
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -137,7 +141,8 @@ int wrt_scene_commit(wrt_ctx* ctx);
    per-bounce colours to accum[(x*height + y)*3 + c] (device pointer, float32,
    the reference's x-major pixel order, y = 0 at the bottom).
    path_colours: optional device pointer [width*height*(s_end-s_begin)][4]
-   receiving (r, g, b, segments traced) per path in ray-id order
+   receiving (r, g, b, segments traced [+100 when the path was still alive at
+   the bounce limit]) per path in ray-id order
    r = (x*height + y)*S + s (main.py:102-104); NULL = library workspace.
    Statistics accumulate in the context (wrt_stats_read). */
 int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces,

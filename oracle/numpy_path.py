@@ -50,6 +50,11 @@ def camera_basis(position, lookat, focus_dist, aperture, aspect_ratio, horizonta
 def generate_rays(cam, width, height, samples, seed, s_begin=0):
     """-> origins, dirs: (W*H*S, 3) float32 in ray-id order."""
     x, y, s = path_identity(width, height, samples, s_begin)
+    return generate_rays_for(cam, width, height, x, y, s, seed)
+
+
+def generate_rays_for(cam, width, height, x, y, s, seed):
+    """Camera rays of the paths named by pixel (x, y) and global sample index s."""
     n = x.shape[0]
     jitter = keyed_rng.keyed_uniform3(seed, x, y, s, keyed_rng.JITTER, 0, 0, 0.0, 1.0)
     # float32 pixel index + float64 offset, stored float32; then a float32 divide
@@ -327,7 +332,17 @@ def render(scene, width, height, samples, max_bounces, seed, s_begin=0, t_min=T_
     """-> dict(image (W,H,3) sqrt-gamma, sample_sum (W,H,3), path_colours (N,3),
                counts (B+1,) active rays entering each bounce, segments (N,))."""
     x, y, s = path_identity(width, height, samples, s_begin)
-    o, d = generate_rays(scene["camera"], width, height, samples, seed, s_begin)
+    r = trace_paths(scene, width, height, x, y, s, max_bounces, seed, t_min, t_max, trace)
+    stacked = r["path_colours"].reshape(width, height, samples, 3)
+    r.update(image=np.sqrt(np.mean(stacked, axis=2)), sample_sum=np.sum(stacked, axis=2, dtype=np.single))
+    return r
+
+
+def trace_paths(scene, width, height, x, y, s, max_bounces, seed, t_min=T_MIN, t_max=T_MAX, trace=None):
+    """The bounce loop for an arbitrary set of paths (pixel x, y and global
+    sample index s per path) of a width x height image.
+    -> dict(path_colours (n,3), counts (B+1,), segments (n,))."""
+    o, d = generate_rays_for(scene["camera"], width, height, x, y, s, seed)
     n = o.shape[0]
     colours = np.ones((n, max_bounces + 1, 3), dtype=np.single)
     horizon, zenith = scene["sky"]["horizon"], scene["sky"]["zenith"]
@@ -360,7 +375,4 @@ def render(scene, width, height, samples, max_bounces, seed, s_begin=0, t_min=T_
                               out_o=o[active].copy(), out_d=d[active].copy(),
                               colour=colours[active, bounce].copy(), absorbed=absorbed.copy()))
         active = active[rec["hit"] & ~absorbed]
-    path_colours = np.prod(colours, axis=1)
-    stacked = path_colours.reshape(width, height, samples, 3)
-    return dict(image=np.sqrt(np.mean(stacked, axis=2)), sample_sum=np.sum(stacked, axis=2, dtype=np.single),
-                path_colours=path_colours, counts=np.array(counts, dtype=np.int64), segments=segments)
+    return dict(path_colours=np.prod(colours, axis=1), counts=np.array(counts, dtype=np.int64), segments=segments)

@@ -23,19 +23,52 @@ struct RenderArgs {
     long long n_batches;          // 8x8-pixel tile x sample batches of 64 paths
 };
 
-static constexpr int RENDER_BLOCK = 256;
+#ifndef WRT_RENDER_BLOCK
+#define WRT_RENDER_BLOCK 256
+#endif
+#ifndef WRT_LDS_CAP_BYTES
+#define WRT_LDS_CAP_BYTES (64 * 1024)
+#endif
+static constexpr int RENDER_BLOCK = WRT_RENDER_BLOCK;
+static constexpr int LDS_CAP_VECS = WRT_LDS_CAP_BYTES / 16;   // f32x4 records a workgroup keeps in LDS
 static constexpr int STAT_PATHS = WRT_MAX_BOUNCES + 2;
 // paths[.].w = segments traced, plus this mark when the path was still alive
 // at the bounce limit (it then also counts as a ray entering bounce max_bounces)
 static constexpr int SURVIVOR_MARK = 100;
 
 // The bounce loop of main.render() (main.py:93-220) as one persistent kernel.
+//
 // A wavefront owns a fixed, interleaved stream of 64-path batches (one 8x8
-// pixel tile at one sample index each).  Every lane carries one path; each
-// trip of the loop traces one segment for all live lanes, then lanes whose
-// path ended (miss, absorbed, bounce limit) are refilled from the stream, so
-// the wavefront stays full until its stream runs dry.
-__global__ __launch_bounds__(RENDER_BLOCK) void k_render(const SceneRec S, const RenderArgs A) {
+// pixel tile at one sample index each) and every lane carries one path.  A
+// lane's segment walks the scene's groups in order.  Small groups, disks and
+// the bounding-sphere culls are evaluated by the lane on its own; a lane that
+// reaches a large group (many spheres, or a triangle group whose cull it
+// passed) PARKS there.  The expensive wave-uniform loop over a group's
+// primitives runs only when enough lanes are parked at it (or nothing else
+// can make progress), so the loop that dominates the run time executes with
+// nearly full wavefronts even though paths end, miss the cull and get
+// refilled at different times.  Finished segments are shaded, ended paths are
+// written out and their lanes refilled from the stream.
+enum { LANE_DEAD = 0, LANE_ADVANCE = 1, LANE_PARKED = 2 };
+
+static constexpr int CHEAP_GROUP_MAX = 8;      // groups up to this size are evaluated per lane
+static constexpr int TRIP_COST = 1500;         // wave-instructions of one shade/refill/advance trip (estimate)
+static constexpr int TRIANGLE_COST = 60;       // wave-instructions per primitive of the uniform loops (estimate)
+static constexpr int SPHERE_COST = 25;
+
+// 8 waves per SIMD (64 VGPRs): the shading code spills to scratch, the group
+// loops do not, and the extra waves hide the scalar-load and branch latencies
+// of the loops (+11 % over 4 waves per SIMD on the bunny workload)
+#ifndef WRT_WAVES_PER_SIMD
+#define WRT_WAVES_PER_SIMD 8
+#endif
+__global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const SceneRec S, const RenderArgs A) {
+    // primitive records of the large groups that fit: copied once per workgroup, then
+    // read by every wave with uniform (broadcast) addresses
+    extern __shared__ f32x4 lds_records[];
+    for (int i = threadIdx.x; i < S.lds_vecs; i += RENDER_BLOCK) lds_records[i] = S.lds_image[i];
+    __syncthreads();
+
     const unsigned lane = threadIdx.x & 63u;
     const long long wave = ((long long)blockIdx.x * RENDER_BLOCK + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * RENDER_BLOCK) >> 6;
@@ -43,73 +76,42 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(const SceneRec S, const
     const long long my_batches = (A.n_batches > wave) ? (A.n_batches - wave + n_waves - 1) / n_waves : 0;
     const long long stream_len = my_batches * 64;
     long long cursor = 0;
+    const int n_groups = S.n_groups;
+    const float sentinel = A.t_max + 1.0f;
+    const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
 
-    bool live = false;
+    int state = LANE_DEAD;
+    int g = 0;                         // next group of the current segment
+    Closest best = {sentinel, -1, -1};
     PathKey key;
     key.k0 = A.k0; key.k1 = A.k1; key.x = key.y = key.s = 0;
     int bounce = 0;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    Ray ray = {0, 0, 0, 0, 0, 1};
     float cr = 1, cg = 1, cb = 1;
     long long out_index = 0;
-    PairCounts pc = {0, 0, 0, 0};
+    PairCounts pc = {0, 0, 0, 0, 0, 0};
+    unsigned lane_sphere = 0, lane_triangle = 0, lane_cull = 0, lane_disk = 0;   // per-lane tallies
 
     while (true) {
-        // ---- refill dead lanes from the stream --------------------------
-        const unsigned long long dead = __ballot(!live);
-        if (dead != 0ull && cursor < stream_len) {
-            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
-            const long long e = cursor + rank;
-            if (!live && e < stream_len) {
-                const long long batch = (e >> 6) * n_waves + wave;
-                const unsigned in_tile = (unsigned)(e & 63);
-                const long long tile = batch / A.n_samples;
-                const int s_local = (int)(batch - tile * A.n_samples);
-                const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
-                const int x = tx * 8 + (int)(in_tile & 7u), y = ty * 8 + (int)(in_tile >> 3);
-                if (x < A.width && y < A.height) {
-                    key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)(A.s_begin + s_local);
-                    float o[3], d[3];
-                    camera_ray(*S.cam, A.width, A.height, key, o, d);
-                    ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
-                    cr = cg = cb = 1.0f;
-                    bounce = 0;
-                    out_index = ((long long)x * A.height + y) * A.n_samples + s_local;
-                    live = true;
-                }
-            }
-            cursor += __popcll(dead);
-        }
-        if (live && A.max_bounces == 0) {
-            // bounce 0 is already the limit: the reference zeroes the path untraced (main.py:211-212)
-            f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
-            reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
-            live = false;
-        }
-        if (__ballot(live) == 0ull) {
-            if (cursor >= stream_len) break;
-            continue;
-        }
-        // ---- one segment for every live lane ------------------------------
-        Closest best;
-        closest_hit(S, 0, S.n_groups, live, ox, oy, oz, dx, dy, dz, A.t_min, A.t_max, best, pc);
-        if (live) {
+        // ---- (a) segments that have seen every group: shade, scatter or end --
+        if (state == LANE_ADVANCE && g == n_groups) {
             bool done;
             if (best.t < A.t_max) {
                 HitRecord h;
-                shade_record(S, best, ox, oy, oz, dx, dy, dz, h);
+                shade_record(S, best, ray, h);
                 const MaterialRec& M = S.materials[h.material];
                 done = false;
                 if (M.kind != WRT_MAT_NONE) {
                     Scattered sc;
-                    scatter_one(S, M, key, (uint32_t)bounce, dx, dy, dz, h, sc);
-                    ox = h.p[0]; oy = h.p[1]; oz = h.p[2];
-                    dx = sc.d[0]; dy = sc.d[1]; dz = sc.d[2];
+                    scatter_one(S, M, key, (uint32_t)bounce, ray.dx, ray.dy, ray.dz, h, sc);
+                    ray.ox = h.p[0]; ray.oy = h.p[1]; ray.oz = h.p[2];
+                    ray.dx = sc.d[0]; ray.dy = sc.d[1]; ray.dz = sc.d[2];
                     cr *= sc.col[0]; cg *= sc.col[1]; cb *= sc.col[2];
                     done = sc.absorbed;
                 }
             } else {
                 // sky, main.py:206-207
-                const float ts = (dy + 1.0f) * 0.5f;
+                const float ts = (ray.dy + 1.0f) * 0.5f;
                 cr *= (1.0f - ts) * S.horizon[0] + ts * S.zenith[0];
                 cg *= (1.0f - ts) * S.horizon[1] + ts * S.zenith[1];
                 cb *= (1.0f - ts) * S.horizon[2] + ts * S.zenith[2];
@@ -125,15 +127,129 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(const SceneRec S, const
             if (done) {
                 f32x4 rec = {cr, cg, cb, (float)mark};
                 reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
-                live = false;
+                state = LANE_DEAD;
+            } else {
+                g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
             }
         }
+        // ---- (b) refill dead lanes from the stream ---------------------------
+        const unsigned long long dead = __ballot(state == LANE_DEAD);
+        if (dead != 0ull && cursor < stream_len) {
+            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+            const long long e = cursor + rank;
+            if (state == LANE_DEAD && e < stream_len) {
+                const long long batch = (e >> 6) * n_waves + wave;
+                const unsigned in_tile = (unsigned)(e & 63);
+                const long long tile = batch / A.n_samples;
+                const int s_local = (int)(batch - tile * A.n_samples);
+                const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
+                const int x = tx * 8 + (int)(in_tile & 7u), y = ty * 8 + (int)(in_tile >> 3);
+                if (x < A.width && y < A.height) {
+                    out_index = ((long long)x * A.height + y) * A.n_samples + s_local;
+                    if (A.max_bounces == 0) {
+                        // bounce 0 is already the limit: zeroed untraced (main.py:211-212)
+                        f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
+                        reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
+                    } else {
+                        key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)(A.s_begin + s_local);
+                        float o[3], d[3];
+                        camera_ray(*S.cam, A.width, A.height, key, o, d);
+                        ray.ox = o[0]; ray.oy = o[1]; ray.oz = o[2]; ray.dx = d[0]; ray.dy = d[1]; ray.dz = d[2];
+                        cr = cg = cb = 1.0f;
+                        bounce = 0;
+                        g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
+                        state = LANE_ADVANCE;
+                    }
+                }
+            }
+            cursor += __popcll(dead);
+        }
+        // ---- (c) walk the groups a lane can handle on its own ----------------
+        while (state == LANE_ADVANCE && g < n_groups) {
+            const GroupRec& G = S.groups[g];
+            const int type = G.type, first = G.first, count = G.count;
+            if (type == GROUP_TRIANGLES) {
+                ++lane_cull;
+                if (!cull_pass(ray, G.c[0], G.c[1], G.c[2], G.c[3])) { ++g; continue; }
+                if (count > CHEAP_GROUP_MAX) { state = LANE_PARKED; break; }
+                lane_triangle += (unsigned)count;
+                lane_triangles(S, g, first, count, ray, A.t_min, A.t_max, best);
+            } else if (type == GROUP_SPHERES) {
+                if (count > CHEAP_GROUP_MAX) { state = LANE_PARKED; break; }
+                lane_sphere += (unsigned)count;
+                lane_spheres(S, g, first, count, ray, A.t_min, sentinel, best);
+            } else {
+                ++lane_disk;
+                float t;
+                if (disk_hit(ray, G.c, G.n, A.t_min, A.t_max, sentinel, t) && t < best.t) {
+                    best.t = t; best.group = g; best.prim = 0;
+                }
+            }
+            ++g;
+        }
+        // ---- (d) run one large group's loop when it pays ---------------------
+        const unsigned long long parked = __ballot(state == LANE_PARKED);
+        const bool more_cheap = (__ballot(state == LANE_ADVANCE) != 0ull) ||
+                                ((__ballot(state == LANE_DEAD) != 0ull) && cursor < stream_len);
+        if (parked == 0ull) {
+            if (!more_cheap) break;
+            continue;
+        }
+        // the group most lanes are parked at (at most four candidates looked at)
+        int run_g = -1, run_n = 0;
+        unsigned long long rest = parked;
+        for (int k = 0; k < 4 && rest != 0ull; ++k) {
+            const int cand = __builtin_amdgcn_readlane(g, (int)__builtin_ctzll(rest));
+            const unsigned long long same = __ballot(state == LANE_PARKED && g == cand);
+            const int n = (int)__popcll(same);
+            if (n > run_n) { run_n = n; run_g = cand; }
+            rest &= ~same;
+        }
+        const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
+        const int lds_base = ugroups[run_g].lds_base;
+        if (more_cheap) {
+            const long long loop_cost = (long long)count * (type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
+            long long need = 64 - (64ll * TRIP_COST) / loop_cost;
+            need = need < 8 ? 8 : need;
+            if (run_n < need) continue;
+        }
+        const bool mine = (state == LANE_PARKED) && (g == run_g);
+        if (type == GROUP_TRIANGLES) {
+            pc.triangle += (unsigned long long)run_n * (unsigned)count;
+            pc.triangle_slots += 64ull * (unsigned)count;
+            if (lds_base >= 0)
+                loop_triangles(LdsTriangles{lds_records + lds_base,
+                                            reinterpret_cast<const float*>(lds_records + lds_base + 2 * count)},
+                               run_g, first, count, mine, ray, A.t_min, A.t_max, best);
+            else
+                loop_triangles(ScalarTriangles{as_uniform(S.tri) + 2 * first, as_uniform(S.tri_bz) + first}, run_g,
+                               first, count, mine, ray, A.t_min, A.t_max, best);
+        } else {
+            pc.sphere += (unsigned long long)run_n * (unsigned)count;
+            pc.sphere_slots += 64ull * (unsigned)count;
+            if (lds_base >= 0)
+                loop_spheres(LdsSpheres{lds_records + lds_base}, run_g, first, count, mine, ray, A.t_min, sentinel,
+                             best);
+            else
+                loop_spheres(ScalarSpheres{as_uniform(S.sph) + first}, run_g, first, count, mine, ray, A.t_min,
+                             sentinel, best);
+        }
+        if (mine) { state = LANE_ADVANCE; ++g; }
+    }
+    // tallies: one atomic per counter per wave
+    unsigned long long t_sphere = lane_sphere, t_triangle = lane_triangle, t_cull = lane_cull, t_disk = lane_disk;
+    for (int off = 32; off > 0; off >>= 1) {
+        t_sphere += __shfl_down(t_sphere, off); t_triangle += __shfl_down(t_triangle, off);
+        t_cull += __shfl_down(t_cull, off); t_disk += __shfl_down(t_disk, off);
     }
     if (lane == 0) {
+        pc.sphere += t_sphere; pc.triangle += t_triangle; pc.cull += t_cull; pc.disk += t_disk;
         if (pc.sphere) atomicAdd(&A.stats[STAT_PATHS + 1], pc.sphere);
         if (pc.triangle) atomicAdd(&A.stats[STAT_PATHS + 2], pc.triangle);
         if (pc.cull) atomicAdd(&A.stats[STAT_PATHS + 3], pc.cull);
         if (pc.disk) atomicAdd(&A.stats[STAT_PATHS + 4], pc.disk);
+        if (pc.sphere_slots) atomicAdd(&A.stats[STAT_PATHS + 5], pc.sphere_slots);
+        if (pc.triangle_slots) atomicAdd(&A.stats[STAT_PATHS + 6], pc.triangle_slots);
     }
 }
 
@@ -199,15 +315,15 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, 
                                                    float t_max, IntersectOut O) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    Ray ray = {0, 0, 0, 0, 0, 1};
     if (live) {
-        ox = origins[i * 3]; oy = origins[i * 3 + 1]; oz = origins[i * 3 + 2];
-        dx = dirs[i * 3]; dy = dirs[i * 3 + 1]; dz = dirs[i * 3 + 2];
+        ray.ox = origins[i * 3]; ray.oy = origins[i * 3 + 1]; ray.oz = origins[i * 3 + 2];
+        ray.dx = dirs[i * 3]; ray.dy = dirs[i * 3 + 1]; ray.dz = dirs[i * 3 + 2];
     }
     Closest best;
-    PairCounts pc = {0, 0, 0, 0};
+    PairCounts pc = {0, 0, 0, 0, 0, 0};
     const int g0 = group < 0 ? 0 : group, g1 = group < 0 ? S.n_groups : group + 1;
-    closest_hit(S, g0, g1, live, ox, oy, oz, dx, dy, dz, t_min, t_max, best, pc);
+    closest_hit(S, g0, g1, live, ray, t_min, t_max, best, pc);
     if (!live) return;
     const bool hit = best.t < t_max;
     HitRecord h;
@@ -215,7 +331,7 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, 
     h.uv[0] = h.uv[1] = 0.0f; h.material = 255; h.back = false;
     int prim = -1, grp = -1;
     if (hit) {
-        shade_record(S, best, ox, oy, oz, dx, dy, dz, h);
+        shade_record(S, best, ray, h);
         grp = best.group;
         prim = best.prim - S.groups[best.group].first;
         if (S.groups[best.group].type == GROUP_DISK) prim = 0;
@@ -268,8 +384,10 @@ struct wrt_ctx {
     std::vector<float> h_sph_radius;
     std::vector<uint8_t> h_sph_material;
     std::vector<f32x4> h_tri;
+    std::vector<float> h_tri_bz;
     std::vector<f32x4> h_tri_shade;
     std::vector<GroupRec> h_groups;
+    std::vector<f32x4> h_lds_image;
     MaterialRec h_materials[WRT_MAX_MATERIALS];
     float* d_textures[WRT_MAX_TEXTURES] = {nullptr};
     TextureRec h_textures[WRT_MAX_TEXTURES];
@@ -282,7 +400,6 @@ struct wrt_ctx {
     unsigned long long* d_stats = nullptr;
     float* d_paths = nullptr;
     size_t paths_bytes = 0;
-    int render_blocks = 0;
     // optional timing of the bounce kernel alone (wrt_profile_*)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
@@ -317,7 +434,7 @@ static int fetch(wrt_ctx* ctx, std::vector<T>& dst, const T* src, size_t n) {
 
 static void reset_scene(wrt_ctx* ctx) {
     ctx->h_sph.clear(); ctx->h_sph_radius.clear(); ctx->h_sph_material.clear();
-    ctx->h_tri.clear(); ctx->h_tri_shade.clear(); ctx->h_groups.clear();
+    ctx->h_tri.clear(); ctx->h_tri_bz.clear(); ctx->h_tri_shade.clear(); ctx->h_groups.clear();
     std::memset(ctx->h_materials, 0, sizeof(ctx->h_materials));
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
     std::memset(&ctx->h_cam, 0, sizeof(ctx->h_cam));
@@ -352,10 +469,11 @@ int wrt_create(int device, wrt_ctx** out) {
         delete ctx;
         return fail(nullptr, WRT_E_HIP, std::string("stats alloc: ") + hipGetErrorString(e));
     }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, RENDER_BLOCK, 0) != hipSuccess || per_cu < 1)
-        per_cu = 2;
-    ctx->render_blocks = ctx->cus * per_cu;
+    if ((e = hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 WRT_LDS_CAP_BYTES)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, WRT_E_HIP, std::string("LDS attribute: ") + hipGetErrorString(e));
+    }
     std::memset(ctx->h_textures, 0, sizeof(ctx->h_textures));
     reset_scene(ctx);
     *out = ctx;
@@ -431,14 +549,15 @@ int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const
         if (int r = fetch(ctx, v[k], src[k], (size_t)count * (k < 6 ? 3 : 2))) return r;
     GroupRec g;
     std::memset(&g, 0, sizeof(g));
-    g.type = GROUP_TRIANGLES; g.first = (int)(ctx->h_tri.size() / 3); g.count = count; g.material = material_id;
+    g.type = GROUP_TRIANGLES; g.first = (int)(ctx->h_tri.size() / 2); g.count = count; g.material = material_id;
     g.c[0] = bounds_centre[0]; g.c[1] = bounds_centre[1]; g.c[2] = bounds_centre[2];
     const float br2 = bounds_radius * bounds_radius;   // self.bounds_radius**2, float32
     g.c[3] = br2;
     for (int i = 0; i < count; ++i) {
         const float* P = &v[0][3 * i]; const float* a = &v[1][3 * i]; const float* b = &v[2][3 * i];
-        f32x4 r0 = {P[0], P[1], P[2], a[0]}, r1 = {a[1], a[2], b[0], b[1]}, r2 = {b[2], 0.0f, 0.0f, 0.0f};
-        ctx->h_tri.push_back(r0); ctx->h_tri.push_back(r1); ctx->h_tri.push_back(r2);
+        f32x4 r0 = {P[0], P[1], P[2], a[0]}, r1 = {a[1], a[2], b[0], b[1]};
+        ctx->h_tri.push_back(r0); ctx->h_tri.push_back(r1);
+        ctx->h_tri_bz.push_back(b[2]);
         const float* m0 = &v[3][3 * i]; const float* m1 = &v[4][3 * i]; const float* m2 = &v[5][3 * i];
         const float* t0 = &v[6][2 * i]; const float* t1 = &v[7][2 * i]; const float* t2 = &v[8][2 * i];
         f32x4 s0 = {m0[0], m0[1], m0[2], m1[0]}, s1 = {m1[1], m1[2], m2[0], m2[1]},
@@ -532,13 +651,39 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
         if (ctx->h_materials[i].kind == WRT_MAT_TEXTURED && !ctx->h_textures[ctx->h_materials[i].texture].rgb)
             return fail(ctx, WRT_E_STATE, "a textured material names a texture slot that was never set");
+    // LDS image: records of the large groups, in scene order, while they fit
+    ctx->h_lds_image.clear();
+    for (GroupRec& g : ctx->h_groups) {
+        g.lds_base = -1;
+        if (g.type == GROUP_DISK || g.count <= CHEAP_GROUP_MAX) continue;
+        // triangles: 2 x f32x4 each, then the B.z floats (padded to whole f32x4)
+        const size_t z_vecs = ((size_t)g.count + 3) / 4;
+        const size_t vecs = g.type == GROUP_TRIANGLES ? (size_t)g.count * 2 + z_vecs : (size_t)g.count;
+        if (!WRT_USE_LDS || ctx->h_lds_image.size() + vecs > (size_t)LDS_CAP_VECS) continue;
+        g.lds_base = (int)ctx->h_lds_image.size();
+        if (g.type == GROUP_TRIANGLES) {
+            const f32x4* src = &ctx->h_tri[(size_t)g.first * 2];
+            ctx->h_lds_image.insert(ctx->h_lds_image.end(), src, src + (size_t)g.count * 2);
+            for (size_t v = 0; v < z_vecs; ++v) {
+                f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int c = 0; c < 4; ++c)
+                    if (v * 4 + c < (size_t)g.count) z[c] = ctx->h_tri_bz[(size_t)g.first + v * 4 + c];
+                ctx->h_lds_image.push_back(z);
+            }
+        } else {
+            const f32x4* src = &ctx->h_sph[g.first];
+            ctx->h_lds_image.insert(ctx->h_lds_image.end(), src, src + vecs);
+        }
+    }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_sph = up(ctx->h_sph.size() * sizeof(f32x4) + 16), b_rad = up(ctx->h_sph_radius.size() * 4 + 16),
                  b_smat = up(ctx->h_sph_material.size() + 16), b_tri = up(ctx->h_tri.size() * sizeof(f32x4) + 16),
+                 b_bz = up(ctx->h_tri_bz.size() * sizeof(float) + 16),
                  b_shade = up(ctx->h_tri_shade.size() * sizeof(f32x4) + 16),
                  b_grp = up(ctx->h_groups.size() * sizeof(GroupRec) + 16), b_mat = up(sizeof(ctx->h_materials)),
-                 b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam));
-    const size_t total = b_sph + b_rad + b_smat + b_tri + b_shade + b_grp + b_mat + b_tex + b_cam;
+                 b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam)),
+                 b_lds = up(ctx->h_lds_image.size() * sizeof(f32x4) + 16);
+    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_lds;
     if (total > ctx->blob_bytes) {
         if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
@@ -557,11 +702,14 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     S.sph_radius = (const float*)put(ctx->h_sph_radius.data(), ctx->h_sph_radius.size() * 4, b_rad);
     S.sph_material = (const uint8_t*)put(ctx->h_sph_material.data(), ctx->h_sph_material.size(), b_smat);
     S.tri = (const f32x4*)put(ctx->h_tri.data(), ctx->h_tri.size() * sizeof(f32x4), b_tri);
+    S.tri_bz = (const float*)put(ctx->h_tri_bz.data(), ctx->h_tri_bz.size() * sizeof(float), b_bz);
     S.tri_shade = (const f32x4*)put(ctx->h_tri_shade.data(), ctx->h_tri_shade.size() * sizeof(f32x4), b_shade);
     S.groups = (const GroupRec*)put(ctx->h_groups.data(), ctx->h_groups.size() * sizeof(GroupRec), b_grp);
     S.materials = (const MaterialRec*)put(ctx->h_materials, sizeof(ctx->h_materials), b_mat);
     S.textures = (const TextureRec*)put(ctx->h_textures, sizeof(ctx->h_textures), b_tex);
     S.cam = (const CameraRec*)put(&ctx->h_cam, sizeof(ctx->h_cam), b_cam);
+    S.lds_image = (const f32x4*)put(ctx->h_lds_image.data(), ctx->h_lds_image.size() * sizeof(f32x4), b_lds);
+    S.lds_vecs = (int)ctx->h_lds_image.size();
     S.n_groups = (int)ctx->h_groups.size();
     HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
     ctx->committed = true;
@@ -609,8 +757,14 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
         A.stats = ctx->d_stats;
         A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
         A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
+        // persistent grid: as many workgroups as stay resident with this scene's LDS image
+        const size_t lds_bytes = (size_t)ctx->scene.lds_vecs * sizeof(f32x4);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, RENDER_BLOCK, lds_bytes) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 1;
         long long waves_wanted = A.n_batches;
-        int blocks = ctx->render_blocks;
+        int blocks = ctx->cus * per_cu;
         const long long blocks_wanted = (waves_wanted + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
         if (blocks_wanted < blocks) blocks = (int)blocks_wanted;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -619,7 +773,7 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
             HIP_TRY(ctx, hipEventCreate(&ev1));
             HIP_TRY(ctx, hipEventRecord(ev0, st));
         }
-        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, ctx->scene, A);
+        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), lds_bytes, st, ctx->scene, A);
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->profiling) {
             HIP_TRY(ctx, hipEventRecord(ev1, st));
@@ -692,6 +846,8 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     out->triangle_pairs = raw[STAT_PATHS + 2];
     out->cull_tests = raw[STAT_PATHS + 3];
     out->disk_pairs = raw[STAT_PATHS + 4];
+    out->sphere_lane_slots = raw[STAT_PATHS + 5];
+    out->triangle_lane_slots = raw[STAT_PATHS + 6];
     return WRT_OK;
 }
 

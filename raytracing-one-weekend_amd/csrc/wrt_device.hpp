@@ -13,6 +13,20 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Build-time variants of the group loops (measured on MI355X, bunny workload,
+// same box: see profiles/): two primitives per trip is +3..17 %; keeping the
+// records in LDS (broadcast ds_read_b128 into VGPRs, with or without the
+// two-register-set pipeline) is 8-13 % slower than scalar loads into SGPRs.
+#ifndef WRT_UNROLL2
+#define WRT_UNROLL2 1
+#endif
+#ifndef WRT_PINGPONG
+#define WRT_PINGPONG 0
+#endif
+#ifndef WRT_USE_LDS
+#define WRT_USE_LDS 0
+#endif
+
 // Wave-uniform read-only data is fetched through the constant address space
 // so that hipcc selects scalar (s_load) instructions and the values arrive
 // in SGPRs, usable directly as VALU operands.
@@ -28,8 +42,10 @@ __device__ __forceinline__ const WRT_CONST T* as_uniform(const T* p) {
 enum { GROUP_SPHERES = 0, GROUP_TRIANGLES = 1, GROUP_DISK = 2 };
 enum { PURPOSE_JITTER = 0, PURPOSE_LENS = 1, PURPOSE_UNITVEC = 2, PURPOSE_SCHLICK = 3 };
 
-struct GroupRec {            // 80 bytes, uniform
+struct GroupRec {            // 96 bytes, uniform
     int type, first, count, material;
+    int lds_base;            // first f32x4 of this group's records in the LDS image, -1 = not resident
+    int pad[3];
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -63,12 +79,15 @@ struct SceneRec {
     const f32x4* sph;          // (cx, cy, cz, r*r) per sphere, all sphere groups concatenated
     const float* sph_radius;
     const uint8_t* sph_material;
-    const f32x4* tri;          // 3 x f32x4 per triangle: (P0, A.x) (A.yz, B.xy) (B.z, 0, 0, 0)
+    const f32x4* tri;          // 2 x f32x4 per triangle: (P0, A.x) (A.yz, B.xy)
+    const float* tri_bz;       // B.z per triangle (kept apart so that no loaded register is unused)
     const f32x4* tri_shade;    // 4 x f32x4 per triangle: n0 n1 n2 (9), uv0 uv1 uv2 (6), pad
     const GroupRec* groups;
     const MaterialRec* materials;
     const TextureRec* textures;   // 16 slots
     const CameraRec* cam;
+    const f32x4* lds_image;       // records of the LDS-resident groups, copied to LDS by the render kernel
+    int lds_vecs;
     float horizon[3], zenith[3];
     int n_groups;
 };
@@ -162,102 +181,289 @@ struct Closest {
     int prim;     // primitive index inside the concatenated sphere / triangle arrays
 };
 
-struct PairCounts { unsigned long long sphere, triangle, cull, disk; };
+struct Ray { float ox, oy, oz, dx, dy, dz; };
 
-// One ray against groups [g_begin, g_end).  Every lane of the wavefront must
-// call this (wave-level votes inside); `live` masks lanes without a ray.
-// Within a group the lowest primitive index wins equal t (numpy.argmin,
-// sphere_group.py:213, triangle_group.py:399); across groups the earlier
-// group wins (strict <, main.py:144).
-__device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int g_end, bool live,
-                                            float ox, float oy, float oz, float dx, float dy, float dz,
+// What the reference would have evaluated, for the roofline accounting
+struct PairCounts { unsigned long long sphere, triangle, cull, disk, sphere_slots, triangle_slots; };
+
+// ---- one (ray, primitive) pair, exactly as the reference evaluates it ------
+// sphere_group.py:137-205.  `s` = (centre, radius^2).
+__device__ __forceinline__ float sphere_discriminant(const Ray& r, float sx, float sy, float sz, float sr2, float& h) {
+    const float cox = r.ox - sx, coy = r.oy - sy, coz = r.oz - sz;
+    h = (r.dx * cox + r.dy * coy) + r.dz * coz;
+    const float c = ((cox * cox + coy * coy) + coz * coz) - sr2;
+    return h * h - c;
+}
+
+__device__ __forceinline__ float sphere_root(float h, float disc, float t_min, float sentinel) {
+    const float root = sqrtf(disc);
+    float t_near = -h - root, t_far = -h + root;
+    t_near = (t_near < t_min) ? sentinel : t_near;
+    t_far = (t_far < t_min) ? sentinel : t_far;
+    return fminf(t_near, t_far);
+}
+
+// triangle_group.py:289-365: numerators of u, v, t and the determinant
+struct TriTerms { float det, un, vn, tn; };
+__device__ __forceinline__ TriTerms triangle_terms(const Ray& r, float P0x, float P0y, float P0z, float Ax, float Ay,
+                                                   float Az, float Bx, float By, float Bz) {
+    TriTerms k;
+    const float p0 = r.dy * Bz - r.dz * By, p1 = r.dz * Bx - r.dx * Bz, p2 = r.dx * By - r.dy * Bx;
+    k.det = (Ax * p0 + Ay * p1) + Az * p2;
+    const float tx = r.ox - P0x, ty = r.oy - P0y, tz = r.oz - P0z;
+    k.un = (tx * p0 + ty * p1) + tz * p2;
+    const float q0 = ty * Az - tz * Ay, q1 = tz * Ax - tx * Az, q2 = tx * Ay - ty * Ax;
+    k.vn = (r.dx * q0 + r.dy * q1) + r.dz * q2;
+    k.tn = (Bx * q0 + By * q1) + Bz * q2;
+    return k;
+}
+
+// triangle_group.py:302-305,315,356,365,372-395: exact u, v, t and the miss predicate
+__device__ __forceinline__ bool triangle_exact(const TriTerms& k, float t_min, float t_max, float& t) {
+    const bool parallel = fabsf(k.det) < 0.00001f;
+    const float inv = 1.0f / (parallel ? 1.0f : k.det);
+    const float u = k.un * inv, v = k.vn * inv;
+    t = k.tn * inv;
+    const bool miss = parallel | (u > 1.0f) | (u < 0.0f) | (v < 0.0f) | ((u + v) > 1.0f) | (t < t_min) | (t > t_max);
+    return !miss;
+}
+
+// bounding-sphere pre-cull, triangle_group.py:158-166 (no t test)
+__device__ __forceinline__ bool cull_pass(const Ray& r, float bx, float by, float bz, float br2) {
+    const float cox = r.ox - bx, coy = r.oy - by, coz = r.oz - bz;
+    const float hh = (r.dx * cox + r.dy * coy) + r.dz * coz;
+    const float cc = ((cox * cox + coy * coy) + coz * coz) - br2;
+    return (hh * hh - cc) > 0.0001f;
+}
+
+// disk.py:48-69; -> hit, t
+__device__ __forceinline__ bool disk_hit(const Ray& r, const float c[4], const float n[4], float t_min, float t_max,
+                                         float sentinel, float& t) {
+    const float ddn = (r.dx * n[0] + r.dy * n[1]) + r.dz * n[2];
+    const float num = ((c[0] - r.ox) * n[0] + (c[1] - r.oy) * n[1]) + (c[2] - r.oz) * n[2];
+    bool ok = fabsf(ddn) > 0.0001f;
+    t = ok ? num / ddn : sentinel;
+    ok = ok && (t > t_min) && (t < t_max);
+    const float rx = (r.ox + r.dx * t) - c[0], ry = (r.oy + r.dy * t) - c[1], rz = (r.oz + r.dz * t) - c[2];
+    return ok && (((rx * rx + ry * ry) + rz * rz) < c[3]);
+}
+
+// ---- wave-uniform loops over one group --------------------------------------
+// All 64 lanes walk the same primitives; the primitive records arrive in
+// SGPRs through scalar loads issued one primitive ahead of their use.  Lanes
+// with `active` false ride along.  Lowest index wins equal t (numpy.argmin,
+// sphere_group.py:213, triangle_group.py:399); an earlier group wins equal t
+// (strict <, main.py:144).
+// Record sources for the loops.  Scalar*: wave-uniform scalar loads, the
+// records arrive in SGPRs and feed the VALU as scalar operands (default).
+// Lds*: broadcast reads of the workgroup's LDS image, the records arrive in
+// VGPRs (WRT_USE_LDS=1; kept for comparison).
+struct TriRec { f32x4 a, b; float bz; };     // a = (P0, A.x), b = (A.y, A.z, B.x, B.y), bz = B.z
+
+struct ScalarSpheres {
+    const WRT_CONST f32x4* p;
+    __device__ __forceinline__ f32x4 operator[](int j) const { return p[j]; }
+};
+struct LdsSpheres {
+    const f32x4* p;
+    __device__ __forceinline__ f32x4 operator[](int j) const { return p[j]; }
+};
+struct ScalarTriangles {
+    const WRT_CONST f32x4* p;
+    const WRT_CONST float* z;
+    __device__ __forceinline__ TriRec operator[](int j) const { return TriRec{p[2 * j], p[2 * j + 1], z[j]}; }
+};
+struct LdsTriangles {
+    const f32x4* p;
+    const float* z;
+    __device__ __forceinline__ TriRec operator[](int j) const { return TriRec{p[2 * j], p[2 * j + 1], z[j]}; }
+};
+
+__device__ __forceinline__ TriTerms triangle_terms(const Ray& r, const TriRec& k) {
+    return triangle_terms(r, k.a.x, k.a.y, k.a.z, k.a.w, k.b.x, k.b.y, k.b.z, k.b.w, k.bz);
+}
+
+template <typename Src>
+__device__ __forceinline__ void loop_spheres(const Src sph, int g, int first, int count, bool active,
+                                             const Ray& r, float t_min, float sentinel, Closest& best) {
+    // inactive lanes can never pass the discriminant test
+    const float thr = active ? 0.00001f : __builtin_inff();
+    int j = 0;
+#if WRT_UNROLL2
+    // two spheres per trip: one wait for the loads, one vote
+    if (count >= 2) {
+        f32x4 na = sph[0], nb = sph[1];
+        for (; j + 1 < count; j += 2) {
+            const f32x4 sa = na, sb = nb;
+            const int jn = (j + 3 < count) ? j + 2 : j;
+            na = sph[jn]; nb = sph[jn + 1];
+            float ha, hb;
+            const float da = sphere_discriminant(r, sa.x, sa.y, sa.z, sa.w, ha);
+            const float db = sphere_discriminant(r, sb.x, sb.y, sb.z, sb.w, hb);
+            if (__ballot(fmaxf(da, db) > thr) != 0ull) {
+                const float ta = sphere_root(ha, da, t_min, sentinel);
+                if (active && da > thr && ta < best.t) { best.t = ta; best.group = g; best.prim = first + j; }
+                const float tb = sphere_root(hb, db, t_min, sentinel);
+                if (active && db > thr && tb < best.t) { best.t = tb; best.group = g; best.prim = first + j + 1; }
+            }
+        }
+    }
+#endif
+    if (j < count) {
+        f32x4 next = sph[j];
+        for (; j < count; ++j) {
+            const f32x4 s = next;
+            next = sph[(j + 1 < count) ? j + 1 : j];
+            float h;
+            const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
+            if (__ballot(disc > thr) != 0ull) {
+                const float t = sphere_root(h, disc, t_min, sentinel);
+                if (active && disc > thr && t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
+            }
+        }
+    }
+}
+
+// Conservative filter for one triangle (1-ulp reciprocal, widened bounds):
+// the returned slack is negative only when the exact evaluation cannot
+// produce a hit closer than t_cap.  One number per pair, so a single compare
+// feeds the wave-level vote.
+__device__ __forceinline__ float triangle_slack(const TriTerms& k, float t_lo, float t_cap) {
+    const float ri = __builtin_amdgcn_rcpf(k.det);
+    const float ua = k.un * ri, va = k.vn * ri, ta = k.tn * ri;
+    const float inside = fminf(fminf(ua, va), 1.00001f - (ua + va)) + 0.00001f;
+    return fminf(fminf(inside, ta - t_lo), t_cap - ta);
+}
+
+// Two triangles at once: shared vote, exact evaluation only when some lane may hit.
+__device__ __forceinline__ void triangle_pair(const TriRec& ra, const TriRec& rb, int g, int prim, bool active,
+                                              const Ray& r, float t_min, float t_max, float t_lo, float t_hi,
+                                              float& t_cap, Closest& best) {
+    const TriTerms ka = triangle_terms(r, ra), kb = triangle_terms(r, rb);
+    const float sa = triangle_slack(ka, t_lo, t_cap), sb = triangle_slack(kb, t_lo, t_cap);
+    if (__ballot(fmaxf(sa, sb) >= 0.0f) != 0ull) {
+        float t;
+        if (triangle_exact(ka, t_min, t_max, t) && active && sa >= 0.0f && t < best.t) {
+            best.t = t; best.group = g; best.prim = prim;
+        }
+        if (triangle_exact(kb, t_min, t_max, t) && active && sb >= 0.0f && t < best.t) {
+            best.t = t; best.group = g; best.prim = prim + 1;
+        }
+        t_cap = active ? fminf(t_hi, best.t * 1.00001f) : -1.0f;
+    }
+}
+
+// `tri[j]` is triangle j of the group.
+template <typename Src>
+__device__ __forceinline__ void loop_triangles(const Src tri, int g, int first, int count, bool active,
+                                               const Ray& r, float t_min, float t_max, Closest& best) {
+    const float t_lo = t_min * 0.99999f, t_hi = t_max * 1.00001f;
+    // inactive lanes get an unreachable cap
+    float t_cap = active ? fminf(t_hi, best.t * 1.00001f) : -1.0f;
+    int j = 0;
+#if WRT_UNROLL2
+#if WRT_PINGPONG
+    // Software pipeline with two register sets: the records of the pair after
+    // next are requested before a pair is evaluated.
+    if (count >= 4) {
+        TriRec x0 = tri[0], x1 = tri[1];
+        for (; j + 3 < count; j += 4) {
+            const TriRec y0 = tri[j + 2], y1 = tri[j + 3];
+            __builtin_amdgcn_sched_barrier(0);      // keep the requests above the arithmetic they overlap with
+            triangle_pair(x0, x1, g, first + j, active, r, t_min, t_max, t_lo, t_hi, t_cap, best);
+            const int jx = (j + 5 < count) ? j + 4 : j;
+            x0 = tri[jx]; x1 = tri[jx + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            triangle_pair(y0, y1, g, first + j + 2, active, r, t_min, t_max, t_lo, t_hi, t_cap, best);
+        }
+    }
+#endif
+    if (j + 1 < count) {
+        TriRec n0 = tri[j], n1 = tri[j + 1];
+        for (; j + 1 < count; j += 2) {
+            const TriRec a = n0, b = n1;
+            const int jn = (j + 3 < count) ? j + 2 : j;
+            n0 = tri[jn]; n1 = tri[jn + 1];
+            triangle_pair(a, b, g, first + j, active, r, t_min, t_max, t_lo, t_hi, t_cap, best);
+        }
+    }
+#endif
+    if (j < count) {
+        TriRec next = tri[j];
+        for (; j < count; ++j) {
+            const TriRec cur = next;
+            next = tri[(j + 1 < count) ? j + 1 : j];
+            const TriTerms k = triangle_terms(r, cur);
+            const float slack = triangle_slack(k, t_lo, t_cap);
+            if (__ballot(slack >= 0.0f) != 0ull) {
+                float t;
+                if (triangle_exact(k, t_min, t_max, t) && active && slack >= 0.0f && t < best.t) {
+                    best.t = t; best.group = g; best.prim = first + j;
+                    t_cap = fminf(t_hi, t * 1.00001f);
+                }
+            }
+        }
+    }
+}
+
+// ---- the same pairs for one lane on its own (small groups, divergent code) ---
+__device__ __forceinline__ void lane_spheres(const SceneRec& S, int g, int first, int count, const Ray& r,
+                                             float t_min, float sentinel, Closest& best) {
+    for (int j = 0; j < count; ++j) {
+        const f32x4 s = S.sph[first + j];
+        float h;
+        const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
+        if (disc > 0.00001f) {
+            const float t = sphere_root(h, disc, t_min, sentinel);
+            if (t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
+        }
+    }
+}
+
+__device__ __forceinline__ void lane_triangles(const SceneRec& S, int g, int first, int count, const Ray& r,
+                                               float t_min, float t_max, Closest& best) {
+    for (int j = 0; j < count; ++j) {
+        const TriRec rec = {S.tri[2 * (first + j)], S.tri[2 * (first + j) + 1], S.tri_bz[first + j]};
+        const TriTerms k = triangle_terms(r, rec);
+        float t;
+        if (triangle_exact(k, t_min, t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
+    }
+}
+
+// One ray per lane against groups [g_begin, g_end), every lane walking the
+// groups together (stage entry point wrt_intersect).  Every lane of the
+// wavefront must call this; `live` masks lanes without a ray.
+__device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int g_end, bool live, const Ray& r,
                                             float t_min, float t_max, Closest& best, PairCounts& pc) {
     const float sentinel = t_max + 1.0f;
-    const float t_lo = t_min * 0.99999f, t_hi = t_max * 1.00001f;
     best.t = sentinel; best.group = -1; best.prim = -1;
     const WRT_CONST GroupRec* groups = as_uniform(S.groups);
-    const WRT_CONST f32x4* sph = as_uniform(S.sph);
-    const WRT_CONST f32x4* tri = as_uniform(S.tri);
     const unsigned long long live_mask = __ballot(live);
     if (live_mask == 0ull) return;
     const unsigned n_live = (unsigned)__popcll(live_mask);
     for (int g = g_begin; g < g_end; ++g) {
         const int type = groups[g].type, first = groups[g].first, count = groups[g].count;
         if (type == GROUP_SPHERES) {
-            // sphere_group.py:137-205
             pc.sphere += (unsigned long long)n_live * (unsigned)count;
-            for (int j = 0; j < count; ++j) {
-                const f32x4 s = sph[first + j];
-                const float cox = ox - s.x, coy = oy - s.y, coz = oz - s.z;
-                const float h = (dx * cox + dy * coy) + dz * coz;
-                const float c = ((cox * cox + coy * coy) + coz * coz) - s.w;
-                const float disc = h * h - c;
-                const bool ok = live && (disc > 0.00001f);
-                if (__ballot(ok) != 0ull) {
-                    const float root = sqrtf(disc);
-                    float t_near = -h - root, t_far = -h + root;
-                    t_near = (t_near < t_min) ? sentinel : t_near;
-                    t_far = (t_far < t_min) ? sentinel : t_far;
-                    const float t = fminf(t_near, t_far);
-                    if (ok && t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
-                }
-            }
+            pc.sphere_slots += 64ull * (unsigned)count;
+            loop_spheres(ScalarSpheres{as_uniform(S.sph) + first}, g, first, count, live, r, t_min, sentinel, best);
         } else if (type == GROUP_TRIANGLES) {
-            // bounding-sphere pre-cull, triangle_group.py:158-166
-            const float bx = groups[g].c[0], by = groups[g].c[1], bz = groups[g].c[2], br2 = groups[g].c[3];
-            const float cox = ox - bx, coy = oy - by, coz = oz - bz;
-            const float hh = (dx * cox + dy * coy) + dz * coz;
-            const float cc = ((cox * cox + coy * coy) + coz * coz) - br2;
-            const bool pass = live && ((hh * hh - cc) > 0.0001f);
+            const bool pass = live && cull_pass(r, groups[g].c[0], groups[g].c[1], groups[g].c[2], groups[g].c[3]);
             const unsigned long long pass_mask = __ballot(pass);
             pc.cull += n_live;
             if (pass_mask == 0ull) continue;
             pc.triangle += (unsigned long long)__popcll(pass_mask) * (unsigned)count;
-            // Moller-Trumbore exactly as triangle_group.py:289-395 evaluates it
-            float t_cap = fminf(t_hi, best.t * 1.00001f);
-            for (int j = 0; j < count; ++j) {
-                const int base = 3 * (first + j);
-                const f32x4 r0 = tri[base], r1 = tri[base + 1], r2 = tri[base + 2];
-                const float P0x = r0.x, P0y = r0.y, P0z = r0.z;
-                const float Ax = r0.w, Ay = r1.x, Az = r1.y;
-                const float Bx = r1.z, By = r1.w, Bz = r2.x;
-                const float p0 = dy * Bz - dz * By, p1 = dz * Bx - dx * Bz, p2 = dx * By - dy * Bx;
-                const float det = (Ax * p0 + Ay * p1) + Az * p2;
-                const float tx = ox - P0x, ty = oy - P0y, tz = oz - P0z;
-                const float un = (tx * p0 + ty * p1) + tz * p2;
-                const float q0 = ty * Az - tz * Ay, q1 = tz * Ax - tx * Az, q2 = tx * Ay - ty * Ax;
-                const float vn = (dx * q0 + dy * q1) + dz * q2;
-                const float tn = (Bx * q0 + By * q1) + Bz * q2;
-                // conservative filter: 1-ulp reciprocal, widened bounds
-                const float ri = __builtin_amdgcn_rcpf(det);
-                const float ua = un * ri, va = vn * ri, ta = tn * ri;
-                const float inside = fminf(fminf(ua, va), 1.00001f - (ua + va));
-                const bool maybe = pass && (inside >= -0.00001f) && (ta >= t_lo) && (ta <= t_cap);
-                if (__ballot(maybe) != 0ull) {
-                    const bool parallel = fabsf(det) < 0.00001f;
-                    const float inv = 1.0f / (parallel ? 1.0f : det);
-                    const float u = un * inv, v = vn * inv, t = tn * inv;
-                    const bool miss = parallel | (u > 1.0f) | (u < 0.0f) | (v < 0.0f) | ((u + v) > 1.0f)
-                                      | (t < t_min) | (t > t_max);
-                    if (maybe && !miss && t < best.t) {
-                        best.t = t; best.group = g; best.prim = first + j;
-                        t_cap = fminf(t_hi, t * 1.00001f);
-                    }
-                }
-            }
+            pc.triangle_slots += 64ull * (unsigned)count;
+            loop_triangles(ScalarTriangles{as_uniform(S.tri) + 2 * first, as_uniform(S.tri_bz) + first}, g, first, count,
+                           pass, r, t_min, t_max, best);
         } else {
-            // disk.py:48-69
             pc.disk += n_live;
-            const float cx = groups[g].c[0], cy = groups[g].c[1], cz = groups[g].c[2], r2 = groups[g].c[3];
-            const float nx = groups[g].n[0], ny = groups[g].n[1], nz = groups[g].n[2];
-            const float ddn = (dx * nx + dy * ny) + dz * nz;
-            const float num = ((cx - ox) * nx + (cy - oy) * ny) + (cz - oz) * nz;
-            bool ok = live && (fabsf(ddn) > 0.0001f);
-            const float t = ok ? num / ddn : sentinel;
-            ok = ok && (t > t_min) && (t < t_max);
-            const float rx = (ox + dx * t) - cx, ry = (oy + dy * t) - cy, rz = (oz + dz * t) - cz;
-            ok = ok && (((rx * rx + ry * ry) + rz * rz) < r2);
-            if (ok && t < best.t) { best.t = t; best.group = g; best.prim = 0; }
+            float c[4], n[4];
+            for (int a = 0; a < 4; ++a) { c[a] = groups[g].c[a]; n[a] = groups[g].n[a]; }
+            float t;
+            if (disk_hit(r, c, n, t_min, t_max, sentinel, t) && live && t < best.t) {
+                best.t = t; best.group = g; best.prim = 0;
+            }
         }
     }
 }
@@ -270,9 +476,8 @@ struct HitRecord {
 
 // Hit point, shading normal, uv, facing and material of the winning
 // primitive (sphere_group.py:225-259, triangle_group.py:414-450, disk.py:65-92).
-__device__ __forceinline__ void shade_record(const SceneRec& S, const Closest& best,
-                                             float ox, float oy, float oz, float dx, float dy, float dz,
-                                             HitRecord& h) {
+__device__ __forceinline__ void shade_record(const SceneRec& S, const Closest& best, const Ray& r, HitRecord& h) {
+    const float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
     const GroupRec& G = S.groups[best.group];
     const float t = best.t;
     h.p[0] = ox + dx * t; h.p[1] = oy + dy * t; h.p[2] = oz + dz * t;
@@ -286,9 +491,8 @@ __device__ __forceinline__ void shade_record(const SceneRec& S, const Closest& b
         h.uv[0] = 0.0f; h.uv[1] = 0.0f;
         h.material = S.sph_material[best.prim];
     } else if (G.type == GROUP_TRIANGLES) {
-        const int base = 3 * best.prim;
-        const f32x4 r0 = S.tri[base], r1 = S.tri[base + 1], r2 = S.tri[base + 2];
-        const float Ax = r0.w, Ay = r1.x, Az = r1.y, Bx = r1.z, By = r1.w, Bz = r2.x;
+        const f32x4 r0 = S.tri[2 * best.prim], r1 = S.tri[2 * best.prim + 1];
+        const float Ax = r0.w, Ay = r1.x, Az = r1.y, Bx = r1.z, By = r1.w, Bz = S.tri_bz[best.prim];
         const float p0 = dy * Bz - dz * By, p1 = dz * Bx - dx * Bz, p2 = dx * By - dy * Bx;
         const float det = (Ax * p0 + Ay * p1) + Az * p2;
         const float inv = 1.0f / det;

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libwrt.so")
+# WRT_LIB selects another build of the same ABI (kernel experiments)
+LIB_PATH = os.environ.get("WRT_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libwrt.so")
 
 MAX_BOUNCES = 62
 MAX_MATERIALS = 256
@@ -40,6 +41,7 @@ class WrtStats(ctypes.Structure):
         ("rays_per_bounce", ctypes.c_uint64 * (MAX_BOUNCES + 2)),
         ("paths", ctypes.c_uint64), ("sphere_pairs", ctypes.c_uint64), ("triangle_pairs", ctypes.c_uint64),
         ("cull_tests", ctypes.c_uint64), ("disk_pairs", ctypes.c_uint64),
+        ("sphere_lane_slots", ctypes.c_uint64), ("triangle_lane_slots", ctypes.c_uint64),
     ]
 
 
@@ -80,6 +82,9 @@ def load_library():
     """dlopen libwrt.so and declare every entry point (no GPU needed)."""
     global _lib
     if _lib is None:
+        # torch first: its bundled HIP runtime must be the one the process uses
+        # (loading the system libamdhip64 before torch leaves torch without devices)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise NativeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                               f"g.build()'` (hipcc --offload-arch=gfx950)")
@@ -318,7 +323,8 @@ class Context:
         self.check(self.lib.wrt_stats_read(self.handle, ctypes.byref(s), self.stream()), "wrt_stats_read")
         return dict(rays_per_bounce=np.array(list(s.rays_per_bounce), dtype=np.int64), paths=int(s.paths),
                     sphere_pairs=int(s.sphere_pairs), triangle_pairs=int(s.triangle_pairs),
-                    cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs))
+                    cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs),
+                    sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots))
 
 
 _contexts = {}

@@ -1,0 +1,67 @@
+// VALU issue-rate microbenchmark for gfx950: cycles per wave64 instruction on one
+// SIMD for plain and packed FP32 ops at 1..8 waves per SIMD.
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench_valu.hip -o gpurun_out/microbench_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define REP 64
+template <int MODE>
+__global__ void k(float* out, long long* cyc, int iters, float seed) {
+    float a[8]; v2f p[8];
+    for (int i = 0; i < 8; ++i) { a[i] = seed + i + threadIdx.x; p[i] = (v2f){a[i], a[i] + 1.f}; }
+    const float m = 1.0001f, c = 0.5f; const v2f pm = {m, m}, pc = {c, c};
+    long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (MODE == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pc));
+                if (MODE == 3) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
+                if (MODE == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+                if (MODE == 5) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "s"(m));
+                if (MODE == 6) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 7) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a[i]), "v"(m) : "vcc");
+                if (MODE == 8) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(m));
+                if (MODE == 9) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(m), "v"(c));
+                if (MODE == 10) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 11) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(m));
+                if (MODE == 12) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
+            }
+        }
+    }
+    long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0; for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+template <int MODE> void run(const char* name) {
+    float* out; long long* cyc; hipMalloc(&out, 4 << 20); hipMalloc(&cyc, 1 << 20);
+    const int iters = 100000;
+    printf("%-14s", name);
+    for (int waves_per_simd : {1, 2, 4, 8}) {
+        int threads = 64 * 4 * waves_per_simd;   // one block per CU, 4 SIMDs
+        int tpb = threads > 1024 ? 1024 : threads; int bpc = threads / tpb;
+        k<MODE><<<256 * bpc, tpb>>>(out, cyc, 10, 1.0f);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0); k<MODE><<<256 * bpc, tpb>>>(out, cyc, iters, 1.0f); hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> h(256 * bpc * tpb / 64); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+        double avg = 0; for (auto v : h) avg += v; avg /= h.size();
+        double inst = (double)iters * REP;
+        // cycles of wave lifetime per instruction / waves per simd = SIMD cycles per instruction
+        printf("  w%d: %.2f ns-cyc@2.4GHz/inst/SIMD (memtime %.2f)", waves_per_simd, ms * 1e-3 * 2.4e9 / (inst * waves_per_simd), avg / inst / waves_per_simd);
+    }
+    printf("\n");
+}
+int main() {
+    run<0>("v_fma_f32"); run<1>("v_mul_f32"); run<2>("v_pk_fma_f32"); run<3>("v_pk_mul_f32");
+    run<4>("v_rcp_f32"); run<5>("v_add_f32 sgpr"); run<6>("v_min3_f32"); run<7>("v_cmp_lt_f32");
+    run<8>("v_mul_f32 sgpr"); run<9>("v_fma_f32 sgpr"); run<10>("v_add_f32 vgpr"); run<11>("v_sub_f32 sgpr"); run<12>("v_fma 2src");
+    run<0>("v_fma_f32 again");
+    return 0;
+}
