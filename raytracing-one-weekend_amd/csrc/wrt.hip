@@ -62,6 +62,20 @@ static constexpr int SPHERE_COST = 25;
 #ifndef WRT_WAVES_PER_SIMD
 #define WRT_WAVES_PER_SIMD 8
 #endif
+// Sum of `count` over the lanes with `take` set (each evaluated `count` pairs of
+// a small group on its own); must be called by the whole wave; wave-uniform result.
+__device__ __forceinline__ unsigned long long wave_sum_small(bool take, int count) {
+    unsigned long long total = 0;
+    unsigned long long rest = __ballot(take);
+    while (rest != 0ull) {                       // one trip per distinct group size present
+        const int c = __builtin_amdgcn_readlane(count, (int)__builtin_ctzll(rest));
+        const unsigned long long same = __ballot(take && count == c);
+        total += (unsigned long long)__popcll(same) * (unsigned)c;
+        rest &= ~same;
+    }
+    return total;
+}
+
 __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const SceneRec S, const RenderArgs A) {
     // primitive records of the large groups that fit: copied once per workgroup, then
     // read by every wave with uniform (broadcast) addresses
@@ -88,9 +102,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     int bounce = 0;
     Ray ray = {0, 0, 0, 0, 0, 1};
     float cr = 1, cg = 1, cb = 1;
-    long long out_index = 0;
     PairCounts pc = {0, 0, 0, 0, 0, 0};
-    unsigned lane_sphere = 0, lane_triangle = 0, lane_cull = 0, lane_disk = 0;   // per-lane tallies
+    // slot of a path in the output, ray-id order r = (x*H + y)*S + s (main.py:102-104)
+    auto out_slot = [&](const PathKey& k) {
+        return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
+    };
 
     while (true) {
         // ---- (a) segments that have seen every group: shade, scatter or end --
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             }
             if (done) {
                 f32x4 rec = {cr, cg, cb, (float)mark};
-                reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
+                reinterpret_cast<f32x4*>(A.paths)[out_slot(key)] = rec;
                 state = LANE_DEAD;
             } else {
                 g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
@@ -145,13 +161,12 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
                 const int x = tx * 8 + (int)(in_tile & 7u), y = ty * 8 + (int)(in_tile >> 3);
                 if (x < A.width && y < A.height) {
-                    out_index = ((long long)x * A.height + y) * A.n_samples + s_local;
+                    key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)(A.s_begin + s_local);
                     if (A.max_bounces == 0) {
                         // bounce 0 is already the limit: zeroed untraced (main.py:211-212)
                         f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
-                        reinterpret_cast<f32x4*>(A.paths)[out_index] = rec;
+                        reinterpret_cast<f32x4*>(A.paths)[out_slot(key)] = rec;
                     } else {
-                        key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)(A.s_begin + s_local);
                         float o[3], d[3];
                         camera_ray(*S.cam, A.width, A.height, key, o, d);
                         ray.ox = o[0]; ray.oy = o[1]; ray.oz = o[2]; ray.dx = d[0]; ray.dy = d[1]; ray.dz = d[2];
@@ -165,27 +180,46 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             cursor += __popcll(dead);
         }
         // ---- (c) walk the groups a lane can handle on its own ----------------
-        while (state == LANE_ADVANCE && g < n_groups) {
-            const GroupRec& G = S.groups[g];
-            const int type = G.type, first = G.first, count = G.count;
-            if (type == GROUP_TRIANGLES) {
-                ++lane_cull;
-                if (!cull_pass(ray, G.c[0], G.c[1], G.c[2], G.c[3])) { ++g; continue; }
-                if (count > CHEAP_GROUP_MAX) { state = LANE_PARKED; break; }
-                lane_triangle += (unsigned)count;
-                lane_triangles(S, g, first, count, ray, A.t_min, A.t_max, best);
-            } else if (type == GROUP_SPHERES) {
-                if (count > CHEAP_GROUP_MAX) { state = LANE_PARKED; break; }
-                lane_sphere += (unsigned)count;
-                lane_spheres(S, g, first, count, ray, A.t_min, sentinel, best);
-            } else {
-                ++lane_disk;
-                float t;
-                if (disk_hit(ray, G.c, G.n, A.t_min, A.t_max, sentinel, t) && t < best.t) {
-                    best.t = t; best.group = g; best.prim = 0;
+        // The loop is wave-uniform (it runs while any lane still advances) so that the
+        // tallies can be kept in scalar registers.
+        while (true) {
+            const bool adv = (state == LANE_ADVANCE) && (g < n_groups);
+            if (__ballot(adv) == 0ull) break;
+            int type = -1, first = 0, count = 0;
+            bool small = false;
+            if (adv) {
+                const GroupRec& G = S.groups[g];
+                type = G.type; first = G.first; count = G.count;
+                if (type == GROUP_TRIANGLES) {
+                    if (!cull_pass(ray, G.c[0], G.c[1], G.c[2], G.c[3])) {
+                        ++g; count = 0;                       // culled: next group
+                    } else if (count > CHEAP_GROUP_MAX) {
+                        state = LANE_PARKED; count = 0;
+                    } else {
+                        small = true;
+                        lane_triangles(S, g, first, count, ray, A.t_min, A.t_max, best);
+                        ++g;
+                    }
+                } else if (type == GROUP_SPHERES) {
+                    if (count > CHEAP_GROUP_MAX) {
+                        state = LANE_PARKED; count = 0;
+                    } else {
+                        small = true;
+                        lane_spheres(S, g, first, count, ray, A.t_min, sentinel, best);
+                        ++g;
+                    }
+                } else {
+                    float t;
+                    if (disk_hit(ray, G.c, G.n, A.t_min, A.t_max, sentinel, t) && t < best.t) {
+                        best.t = t; best.group = g; best.prim = 0;
+                    }
+                    ++g;
                 }
             }
-            ++g;
+            pc.cull += __popcll(__ballot(type == GROUP_TRIANGLES));
+            pc.disk += __popcll(__ballot(type == GROUP_DISK));
+            pc.triangle += wave_sum_small(small && type == GROUP_TRIANGLES, count);
+            pc.sphere += wave_sum_small(small && type == GROUP_SPHERES, count);
         }
         // ---- (d) run one large group's loop when it pays ---------------------
         const unsigned long long parked = __ballot(state == LANE_PARKED);
@@ -237,13 +271,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         if (mine) { state = LANE_ADVANCE; ++g; }
     }
     // tallies: one atomic per counter per wave
-    unsigned long long t_sphere = lane_sphere, t_triangle = lane_triangle, t_cull = lane_cull, t_disk = lane_disk;
-    for (int off = 32; off > 0; off >>= 1) {
-        t_sphere += __shfl_down(t_sphere, off); t_triangle += __shfl_down(t_triangle, off);
-        t_cull += __shfl_down(t_cull, off); t_disk += __shfl_down(t_disk, off);
-    }
     if (lane == 0) {
-        pc.sphere += t_sphere; pc.triangle += t_triangle; pc.cull += t_cull; pc.disk += t_disk;
         if (pc.sphere) atomicAdd(&A.stats[STAT_PATHS + 1], pc.sphere);
         if (pc.triangle) atomicAdd(&A.stats[STAT_PATHS + 2], pc.triangle);
         if (pc.cull) atomicAdd(&A.stats[STAT_PATHS + 3], pc.cull);
