@@ -1,0 +1,137 @@
+"""
+Randomly generated scenes through the C ABI against the CPU oracle: group
+sizes around every code-path boundary of the render kernel (per-lane groups of
+up to 8 primitives, odd and even loop tails, many large groups so that lanes
+park at different groups), all material kinds, disks, depth of field, ragged
+image sizes and sample offsets.
+"""
+import numpy as np
+import pytest
+
+from oracle import numpy_path
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def random_scene(rng, n_groups, sizes):
+    kinds = ["diffuse", "checker", "normal_rgb", "normal_discrete", "metal", "metal_fuzzy", "dielectric", "textured"]
+    materials = {}
+    tex = helpers.load_texture("uv_test.jpg")
+    for i, kind in enumerate(kinds):
+        if kind == "diffuse":
+            materials[i] = dict(kind="diffuse", colour=rng.uniform(0.2, 0.9, 3).astype(np.single))
+        elif kind == "checker":
+            materials[i] = dict(kind="checker", scale=rng.uniform(1, 4, 3), offset=rng.uniform(0, 1, 3),
+                                colour_a=rng.uniform(0.5, 1, 3), colour_b=rng.uniform(0, 0.5, 3))
+        elif kind == "metal":
+            materials[i] = dict(kind="metal", colour=rng.uniform(0.6, 1, 3).astype(np.single), fuzziness=0.0)
+        elif kind == "metal_fuzzy":
+            materials[i] = dict(kind="metal", colour=rng.uniform(0.6, 1, 3).astype(np.single),
+                                fuzziness=float(rng.uniform(0.05, 0.6)))
+        elif kind == "dielectric":
+            materials[i] = dict(kind="dielectric", ior=float(rng.uniform(1.2, 1.8)))
+        elif kind == "textured":
+            materials[i] = dict(kind="textured", pixels=tex, smallest_side=float(min(tex.shape[:2])))
+        else:
+            materials[i] = dict(kind=kind)
+    groups = [dict(type="spheres", centres=np.array([[0, -500.5, 0]], np.single), radii=np.array([500.0], np.single),
+                   materials=np.array([1], np.ubyte))]
+    for gi in range(n_groups):
+        n = sizes[gi % len(sizes)]
+        centre = rng.uniform(-3, 3, 3) * np.array([1, 0.3, 1]) + np.array([0, 1.0, 0])
+        which = rng.integers(0, 3)
+        if which == 0:
+            c = (centre + rng.uniform(-1, 1, (n, 3))).astype(np.single)
+            groups.append(dict(type="spheres", centres=c, radii=rng.uniform(0.1, 0.5, n).astype(np.single),
+                               materials=rng.integers(0, len(kinds) + 1, n).astype(np.ubyte)))   # one index unmapped
+        elif which == 1:
+            p0 = (centre + rng.uniform(-1, 1, (n, 3))).astype(np.single)
+            A = rng.uniform(-0.7, 0.7, (n, 3)).astype(np.single)
+            B = rng.uniform(-0.7, 0.7, (n, 3)).astype(np.single)
+
+            def unit(v):
+                return (v / np.linalg.norm(v, axis=1)[:, None]).astype(np.single)
+            nrm = [unit(np.cross(A, B) + rng.normal(scale=0.2, size=(n, 3))) for _ in range(3)]
+            uv = [rng.uniform(0, 1, (n, 2)).astype(np.single) for _ in range(3)]
+            pts = np.concatenate([p0, p0 + A, p0 + B])
+            bc = np.mean(pts, axis=0).astype(np.single)
+            br = np.single(np.max(np.linalg.norm(pts - bc, axis=1)) * 1.01)
+            groups.append(dict(type="triangles", pt0=p0, A=A, B=B, n0=nrm[0], n1=nrm[1], n2=nrm[2], uv0=uv[0],
+                               uv1=uv[1], uv2=uv[2], material_id=int(rng.integers(0, len(kinds))), bounds_centre=bc,
+                               bounds_radius=br))
+        else:
+            nv = rng.normal(size=3)
+            nv = (nv / np.linalg.norm(nv)).astype(np.single)
+            up = np.array([0, 1, 0], np.single) if abs(nv[1]) < 0.9 else np.array([1, 0, 0], np.single)
+            U = np.cross(up, nv)
+            U = U / np.linalg.norm(U)
+            V = np.cross(nv, U)
+            groups.append(dict(type="disk", centre=centre.astype(np.single), normal=nv, U=U.astype(np.single),
+                               V=V.astype(np.single), radius=float(rng.uniform(0.3, 1.2)),
+                               material_index=int(rng.integers(0, len(kinds)))))
+    cam = numpy_path.camera_basis(np.array([6.0, 3.0, 7.0]), np.array([0.0, 0.8, 0.0]), 9.0,
+                                  float(rng.choice([0.0, 0.3])), 1.7, 45.0)
+    sky = dict(horizon=np.array([1, 1, 1], np.single), zenith=np.array([0.5, 0.7, 1.0], np.single))
+    return dict(camera=cam, groups=groups, materials=materials, sky=sky)
+
+
+class Flat:
+    def __init__(self, rec):
+        self.rec = rec
+
+    def _flat(self):
+        return self.rec
+
+
+@pytest.mark.parametrize("seed,n_groups,sizes", [
+    (1, 3, [1, 2, 3]),
+    (2, 4, [7, 8, 9, 10]),            # around the per-lane / parked boundary
+    (3, 5, [11, 12, 13, 30, 31]),     # odd / even tails of the two-per-trip loops
+    (4, 9, [20, 9, 33]),              # lanes park at many different groups
+    (5, 12, [4, 40, 1, 17]),
+])
+def test_random_scene_matches_oracle(seed, n_groups, sizes):
+    from weekend_raytracer import main
+    rng = np.random.default_rng(seed)
+    scene = random_scene(rng, n_groups, sizes)
+    w, h, s, b, s_begin = 45 + seed, 27, 3, 7, seed
+    want = numpy_path.render(scene, w, h, s, b, seed=1000 + seed, s_begin=s_begin)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    got = main.render_frame(objs, w, h, s, b, seed=1000 + seed, s_begin=s_begin, want_paths=True)
+    same = np.all(got["path_colours"] == want["path_colours"], axis=1)
+    assert same.mean() >= 0.995, same.mean()
+    assert (got["segments"] == want["segments"]).mean() >= 0.995
+    assert helpers.psnr(np.nan_to_num(got["image"]), np.nan_to_num(want["image"])) >= 40.0
+    if same.all():
+        assert np.array_equal(got["counts"], want["counts"])
+    # roofline bookkeeping equals what the reference would evaluate
+    segments = int(got["counts"][:-1].sum())
+    n_sph = sum(g["radii"].shape[0] for g in scene["groups"] if g["type"] == "spheres")
+    n_tri_groups = sum(1 for g in scene["groups"] if g["type"] == "triangles")
+    n_disks = sum(1 for g in scene["groups"] if g["type"] == "disk")
+    st = got["stats"]
+    assert st["sphere_pairs"] == segments * n_sph
+    assert st["cull_tests"] == segments * n_tri_groups
+    assert st["disk_pairs"] == segments * n_disks
+
+
+def test_intersect_entry_point_on_random_scene():
+    from weekend_raytracer import _native
+    rng = np.random.default_rng(77)
+    scene = random_scene(rng, 8, [9, 2, 25, 16])
+    ctx = _native.Context(0)
+    ctx.upload(scene)
+    o = rng.uniform(-6, 6, (5000, 3)).astype(np.single)
+    d = rng.normal(size=(5000, 3))
+    d = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.single)
+    got = ctx.intersect(-1, o, d, 0.001, 1000.0)
+    want = numpy_path.closest_hit(scene["groups"], o, d)
+    assert np.array_equal(got["hit"], want["hit"])
+    hit = want["hit"]
+    for k in ("t", "p", "n", "uv"):
+        assert np.array_equal(got[k][hit], want[k][hit].astype(np.single)), k
+    for k in ("mat", "back", "group", "prim"):
+        assert np.array_equal(got[k][hit], want[k][hit]), k
+    ctx.close()
