@@ -30,6 +30,12 @@ __global__ void k(float* out, long long* cyc, int iters, float seed) {
                 if (MODE == 10) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
                 if (MODE == 11) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "s"(m));
                 if (MODE == 12) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 13) asm volatile("v_mul_f32_dpp %0, %1, %0 row_ror:3 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(m));
+                if (MODE == 14) asm volatile("v_mov_b32_dpp %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(m));
+                if (MODE == 15) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "s"(m));
+                if (MODE == 16) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 17) asm volatile("v_mul_f32 %0, 0x3f800054, %0" : "+v"(a[i]));
+                if (MODE == 18) asm volatile("v_mul_f32 %0, 2.0, %0" : "+v"(a[i]));
             }
         }
     }
@@ -62,6 +68,7 @@ int main() {
     run<0>("v_fma_f32"); run<1>("v_mul_f32"); run<2>("v_pk_fma_f32"); run<3>("v_pk_mul_f32");
     run<4>("v_rcp_f32"); run<5>("v_add_f32 sgpr"); run<6>("v_min3_f32"); run<7>("v_cmp_lt_f32");
     run<8>("v_mul_f32 sgpr"); run<9>("v_fma_f32 sgpr"); run<10>("v_add_f32 vgpr"); run<11>("v_sub_f32 sgpr"); run<12>("v_fma 2src");
+    run<13>("v_mul dpp ror3"); run<14>("v_mov dpp ror1"); run<15>("v_mov sgpr"); run<16>("v_max_f32"); run<17>("v_mul literal"); run<18>("v_mul inline2.0");
     run<0>("v_fma_f32 again");
     return 0;
 }
