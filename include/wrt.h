@@ -84,6 +84,11 @@ typedef struct wrt_stats {
        pairs evaluated there / slots = lane efficiency of the dominant loops */
     uint64_t sphere_lane_slots;
     uint64_t triangle_lane_slots;
+    /* clock tallies of the bounce kernel, zero unless the library was built with
+       -DWRT_TIMING=1 (shader clock ticks, 100 MHz): [0] sum of the wavefronts' lifetimes,
+       [1] longest lifetime, [2] in triangle loops, [3] in sphere loops, [4] shading,
+       [5] refilling lanes, [6] per-lane group walk, [7] group loops run */
+    uint64_t clock_ticks[8];
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */

@@ -19,6 +19,7 @@ struct RenderArgs {
     uint32_t k0, k1;
     float* paths;                 // [width*height*n_samples][4]
     unsigned long long* stats;    // wrt_stats layout
+    unsigned long long* next_batch;   // work counter of this launch, zero at launch
     int tiles_x, tiles_y;
     long long n_batches;          // 8x8-pixel tile x sample batches of 64 paths
 };
@@ -26,11 +27,7 @@ struct RenderArgs {
 #ifndef WRT_RENDER_BLOCK
 #define WRT_RENDER_BLOCK 256
 #endif
-#ifndef WRT_LDS_CAP_BYTES
-#define WRT_LDS_CAP_BYTES (64 * 1024)
-#endif
 static constexpr int RENDER_BLOCK = WRT_RENDER_BLOCK;
-static constexpr int LDS_CAP_VECS = WRT_LDS_CAP_BYTES / 16;   // f32x4 records a workgroup keeps in LDS
 static constexpr int STAT_PATHS = WRT_MAX_BOUNCES + 2;
 // paths[.].w = segments traced, plus this mark when the path was still alive
 // at the bounce limit (it then also counts as a ray entering bounce max_bounces)
@@ -38,8 +35,9 @@ static constexpr int SURVIVOR_MARK = 100;
 
 // The bounce loop of main.render() (main.py:93-220) as one persistent kernel.
 //
-// A wavefront owns a fixed, interleaved stream of 64-path batches (one 8x8
-// pixel tile at one sample index each) and every lane carries one path.  A
+// The work is cut into 64-path batches (one 8x8 pixel tile at one sample index
+// each) that the resident wavefronts take from a counter as their lanes run
+// dry; every lane carries one path.  A
 // lane's segment walks the scene's groups in order.  Small groups, disks and
 // the bounding-sphere culls are evaluated by the lane on its own; a lane that
 // reaches a large group (many spheres, or a triangle group whose cull it
@@ -48,8 +46,20 @@ static constexpr int SURVIVOR_MARK = 100;
 // can make progress), so the loop that dominates the run time executes with
 // nearly full wavefronts even though paths end, miss the cull and get
 // refilled at different times.  Finished segments are shaded, ended paths are
-// written out and their lanes refilled from the stream.
+// written out and their lanes refilled from the wave's current batch.
 enum { LANE_DEAD = 0, LANE_ADVANCE = 1, LANE_PARKED = 2 };
+
+// -DWRT_TIMING=1: every wave tallies where its time goes (wrt_stats.clock_ticks)
+#ifndef WRT_TIMING
+#define WRT_TIMING 0
+#endif
+#if WRT_TIMING
+#define WRT_CLOCK() ((long long)__builtin_readcyclecounter())
+#define WRT_TALLY(slot, since) (ticks[slot] += WRT_CLOCK() - (since))
+#else
+#define WRT_CLOCK() 0ll
+#define WRT_TALLY(slot, since) ((void)(since))
+#endif
 
 static constexpr int CHEAP_GROUP_MAX = 8;      // groups up to this size are evaluated per lane
 static constexpr int TRIP_COST = 1500;         // wave-instructions of one shade/refill/advance trip (estimate)
@@ -77,19 +87,13 @@ __device__ __forceinline__ unsigned long long wave_sum_small(bool take, int coun
 }
 
 __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const SceneRec S, const RenderArgs A) {
-    // primitive records of the large groups that fit: copied once per workgroup, then
-    // read by every wave with uniform (broadcast) addresses
-    extern __shared__ f32x4 lds_records[];
-    for (int i = threadIdx.x; i < S.lds_vecs; i += RENDER_BLOCK) lds_records[i] = S.lds_image[i];
-    __syncthreads();
-
+    __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     const unsigned lane = threadIdx.x & 63u;
-    const long long wave = ((long long)blockIdx.x * RENDER_BLOCK + threadIdx.x) >> 6;
-    const long long n_waves = ((long long)gridDim.x * RENDER_BLOCK) >> 6;
-    // entries of this wave's stream: batches wave, wave + n_waves, ...
-    const long long my_batches = (A.n_batches > wave) ? (A.n_batches - wave + n_waves - 1) / n_waves : 0;
-    const long long stream_len = my_batches * 64;
-    long long cursor = 0;
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0};
+    // the batch this wave is handing out to its lanes and how many of its 64 paths are gone
+    long long batch = 0;
+    unsigned batch_used = 64;
+    bool drained = false;              // the launch has no batch left
     const int n_groups = S.n_groups;
     const float sentinel = A.t_max + 1.0f;
     const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
@@ -108,7 +112,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
     };
 
+    long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long born = WRT_CLOCK();
     while (true) {
+        long long since = WRT_CLOCK();
         // ---- (a) segments that have seen every group: shade, scatter or end --
         if (state == LANE_ADVANCE && g == n_groups) {
             bool done;
@@ -148,14 +155,24 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
             }
         }
-        // ---- (b) refill dead lanes from the stream ---------------------------
-        const unsigned long long dead = __ballot(state == LANE_DEAD);
-        if (dead != 0ull && cursor < stream_len) {
-            const unsigned rank = (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
-            const long long e = cursor + rank;
-            if (state == LANE_DEAD && e < stream_len) {
-                const long long batch = (e >> 6) * n_waves + wave;
-                const unsigned in_tile = (unsigned)(e & 63);
+        WRT_TALLY(4, since); since = WRT_CLOCK();
+        // ---- (b) refill dead lanes: batches come from one counter for the whole launch --
+        // (a fixed share per wave leaves most of the GPU idle while the waves whose
+        // share happened to hold more of the expensive tiles finish)
+        for (int pass = 0; pass < 2; ++pass) {
+            const unsigned long long dead = __ballot(state == LANE_DEAD);
+            if (dead == 0ull || drained) break;
+            if (batch_used == 64) {
+                unsigned long long taken = 0;
+                if (lane == 0) taken = atomicAdd(A.next_batch, 1ull);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)taken);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(taken >> 32));
+                batch = (long long)(((unsigned long long)hi << 32) | lo);
+                if (batch >= A.n_batches) { drained = true; break; }
+                batch_used = 0;
+            }
+            const unsigned in_tile = batch_used + (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
+            if (state == LANE_DEAD && in_tile < 64u) {
                 const long long tile = batch / A.n_samples;
                 const int s_local = (int)(batch - tile * A.n_samples);
                 const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
@@ -177,8 +194,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                     }
                 }
             }
-            cursor += __popcll(dead);
+            const unsigned wanted = batch_used + (unsigned)__popcll(dead);
+            batch_used = wanted < 64u ? wanted : 64u;
         }
+        WRT_TALLY(5, since); since = WRT_CLOCK();
         // ---- (c) walk the groups a lane can handle on its own ----------------
         // The loop is wave-uniform (it runs while any lane still advances) so that the
         // tallies can be kept in scalar registers.
@@ -221,10 +240,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             pc.triangle += wave_sum_small(small && type == GROUP_TRIANGLES, count);
             pc.sphere += wave_sum_small(small && type == GROUP_SPHERES, count);
         }
+        WRT_TALLY(6, since);
         // ---- (d) run one large group's loop when it pays ---------------------
         const unsigned long long parked = __ballot(state == LANE_PARKED);
         const bool more_cheap = (__ballot(state == LANE_ADVANCE) != 0ull) ||
-                                ((__ballot(state == LANE_DEAD) != 0ull) && cursor < stream_len);
+                                ((__ballot(state == LANE_DEAD) != 0ull) && !drained);
         if (parked == 0ull) {
             if (!more_cheap) break;
             continue;
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             rest &= ~same;
         }
         const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
-        const int lds_base = ugroups[run_g].lds_base;
+        const WRT_CONST f32x4* records = as_uniform(S.pairs) + ugroups[run_g].pair_base;
         if (more_cheap) {
             const long long loop_cost = (long long)count * (type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
             long long need = 64 - (64ll * TRIP_COST) / loop_cost;
@@ -248,25 +268,18 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             if (run_n < need) continue;
         }
         const bool mine = (state == LANE_PARKED) && (g == run_g);
+        since = WRT_CLOCK();
+        ticks[7] += WRT_TIMING;
         if (type == GROUP_TRIANGLES) {
             pc.triangle += (unsigned long long)run_n * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
-            if (lds_base >= 0)
-                loop_triangles(LdsTriangles{lds_records + lds_base,
-                                            reinterpret_cast<const float*>(lds_records + lds_base + 2 * count)},
-                               run_g, first, count, mine, ray, A.t_min, A.t_max, best);
-            else
-                loop_triangles(ScalarTriangles{as_uniform(S.tri) + 2 * first, as_uniform(S.tri_bz) + first}, run_g,
-                               first, count, mine, ray, A.t_min, A.t_max, best);
+            loop_triangles(S, records, run_g, first, count, mine, ray, A.t_min, A.t_max, queue, best);
+            WRT_TALLY(2, since);
         } else {
             pc.sphere += (unsigned long long)run_n * (unsigned)count;
             pc.sphere_slots += 64ull * (unsigned)count;
-            if (lds_base >= 0)
-                loop_spheres(LdsSpheres{lds_records + lds_base}, run_g, first, count, mine, ray, A.t_min, sentinel,
-                             best);
-            else
-                loop_spheres(ScalarSpheres{as_uniform(S.sph) + first}, run_g, first, count, mine, ray, A.t_min,
-                             sentinel, best);
+            loop_spheres(S, records, run_g, first, count, mine, ray, A.t_min, sentinel, queue, best);
+            WRT_TALLY(3, since);
         }
         if (mine) { state = LANE_ADVANCE; ++g; }
     }
@@ -278,6 +291,13 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         if (pc.disk) atomicAdd(&A.stats[STAT_PATHS + 4], pc.disk);
         if (pc.sphere_slots) atomicAdd(&A.stats[STAT_PATHS + 5], pc.sphere_slots);
         if (pc.triangle_slots) atomicAdd(&A.stats[STAT_PATHS + 6], pc.triangle_slots);
+#if WRT_TIMING
+        ticks[0] = ticks[1] = WRT_CLOCK() - born;
+        for (int i = 0; i < 8; ++i) {
+            if (i == 1) atomicMax(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
+            else atomicAdd(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
+        }
+#endif
     }
 }
 
@@ -351,7 +371,9 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, 
     Closest best;
     PairCounts pc = {0, 0, 0, 0, 0, 0};
     const int g0 = group < 0 ? 0 : group, g1 = group < 0 ? S.n_groups : group + 1;
-    closest_hit(S, g0, g1, live, ray, t_min, t_max, best, pc);
+    __shared__ unsigned queue_slots[256 / 64][QUEUE_SLOTS][64];
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0};
+    closest_hit(S, g0, g1, live, ray, t_min, t_max, queue, best, pc);
     if (!live) return;
     const bool hit = best.t < t_max;
     HitRecord h;
@@ -415,7 +437,7 @@ struct wrt_ctx {
     std::vector<float> h_tri_bz;
     std::vector<f32x4> h_tri_shade;
     std::vector<GroupRec> h_groups;
-    std::vector<f32x4> h_lds_image;
+    std::vector<f32x4> h_pairs;
     MaterialRec h_materials[WRT_MAX_MATERIALS];
     float* d_textures[WRT_MAX_TEXTURES] = {nullptr};
     TextureRec h_textures[WRT_MAX_TEXTURES];
@@ -426,6 +448,7 @@ struct wrt_ctx {
     void* d_blob = nullptr;
     size_t blob_bytes = 0;
     unsigned long long* d_stats = nullptr;
+    unsigned long long* d_next_batch = nullptr;
     float* d_paths = nullptr;
     size_t paths_bytes = 0;
     // optional timing of the bounce kernel alone (wrt_profile_*)
@@ -493,14 +516,10 @@ int wrt_create(int device, wrt_ctx** out) {
     }
     ctx->cus = prop.multiProcessorCount;
     if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(wrt_stats))) != hipSuccess ||
-        (e = hipMemset(ctx->d_stats, 0, sizeof(wrt_stats))) != hipSuccess) {
+        (e = hipMemset(ctx->d_stats, 0, sizeof(wrt_stats))) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->d_next_batch, 256)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, WRT_E_HIP, std::string("stats alloc: ") + hipGetErrorString(e));
-    }
-    if ((e = hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 WRT_LDS_CAP_BYTES)) != hipSuccess) {
-        delete ctx;
-        return fail(nullptr, WRT_E_HIP, std::string("LDS attribute: ") + hipGetErrorString(e));
     }
     std::memset(ctx->h_textures, 0, sizeof(ctx->h_textures));
     reset_scene(ctx);
@@ -514,6 +533,7 @@ int wrt_destroy(wrt_ctx* ctx) {
     for (float*& t : ctx->d_textures) if (t) { (void)hipFree(t); t = nullptr; }
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_next_batch) (void)hipFree(ctx->d_next_batch);
     if (ctx->d_paths) (void)hipFree(ctx->d_paths);
     for (auto& pr : ctx->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete ctx;
@@ -679,30 +699,32 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
         if (ctx->h_materials[i].kind == WRT_MAT_TEXTURED && !ctx->h_textures[ctx->h_materials[i].texture].rgb)
             return fail(ctx, WRT_E_STATE, "a textured material names a texture slot that was never set");
-    // LDS image: records of the large groups, in scene order, while they fit
-    ctx->h_lds_image.clear();
+    // the group loops' view of the primitives: two per record, component-interleaved; a group
+    // with an odd count ends with its last primitive twice
+    ctx->h_pairs.clear();
     for (GroupRec& g : ctx->h_groups) {
-        g.lds_base = -1;
-        if (g.type == GROUP_DISK || g.count <= CHEAP_GROUP_MAX) continue;
-        // triangles: 2 x f32x4 each, then the B.z floats (padded to whole f32x4)
-        const size_t z_vecs = ((size_t)g.count + 3) / 4;
-        const size_t vecs = g.type == GROUP_TRIANGLES ? (size_t)g.count * 2 + z_vecs : (size_t)g.count;
-        if (!WRT_USE_LDS || ctx->h_lds_image.size() + vecs > (size_t)LDS_CAP_VECS) continue;
-        g.lds_base = (int)ctx->h_lds_image.size();
-        if (g.type == GROUP_TRIANGLES) {
-            const f32x4* src = &ctx->h_tri[(size_t)g.first * 2];
-            ctx->h_lds_image.insert(ctx->h_lds_image.end(), src, src + (size_t)g.count * 2);
-            for (size_t v = 0; v < z_vecs; ++v) {
-                f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                for (int c = 0; c < 4; ++c)
-                    if (v * 4 + c < (size_t)g.count) z[c] = ctx->h_tri_bz[(size_t)g.first + v * 4 + c];
-                ctx->h_lds_image.push_back(z);
+        g.pair_base = (int)ctx->h_pairs.size();
+        if (g.type == GROUP_DISK) continue;
+        for (int j = 0; j < g.count; j += 2) {
+            const size_t a = (size_t)g.first + j, b = (size_t)g.first + (j + 1 < g.count ? j + 1 : j);
+            if (g.type == GROUP_SPHERES) {
+                const f32x4 sa = ctx->h_sph[a], sb = ctx->h_sph[b];
+                ctx->h_pairs.push_back(f32x4{sa.x, sb.x, sa.y, sb.y});
+                ctx->h_pairs.push_back(f32x4{sa.z, sb.z, sa.w, sb.w});
+            } else {
+                // (P0, A.x) (A.yz, B.xy) B.z -> P0x P0y | P0z Ax | Ay Az | Bx By | Bz
+                const f32x4 a0 = ctx->h_tri[2 * a], a1 = ctx->h_tri[2 * a + 1], b0 = ctx->h_tri[2 * b],
+                            b1 = ctx->h_tri[2 * b + 1];
+                ctx->h_pairs.push_back(f32x4{a0.x, b0.x, a0.y, b0.y});
+                ctx->h_pairs.push_back(f32x4{a0.z, b0.z, a0.w, b0.w});
+                ctx->h_pairs.push_back(f32x4{a1.x, b1.x, a1.y, b1.y});
+                ctx->h_pairs.push_back(f32x4{a1.z, b1.z, a1.w, b1.w});
+                ctx->h_pairs.push_back(f32x4{ctx->h_tri_bz[a], ctx->h_tri_bz[b], 0.0f, 0.0f});
             }
-        } else {
-            const f32x4* src = &ctx->h_sph[g.first];
-            ctx->h_lds_image.insert(ctx->h_lds_image.end(), src, src + vecs);
         }
     }
+    // the loops fetch one step past a group's end: keep that read inside the array
+    for (int i = 0; i < 8; ++i) ctx->h_pairs.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_sph = up(ctx->h_sph.size() * sizeof(f32x4) + 16), b_rad = up(ctx->h_sph_radius.size() * 4 + 16),
                  b_smat = up(ctx->h_sph_material.size() + 16), b_tri = up(ctx->h_tri.size() * sizeof(f32x4) + 16),
@@ -710,8 +732,8 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                  b_shade = up(ctx->h_tri_shade.size() * sizeof(f32x4) + 16),
                  b_grp = up(ctx->h_groups.size() * sizeof(GroupRec) + 16), b_mat = up(sizeof(ctx->h_materials)),
                  b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam)),
-                 b_lds = up(ctx->h_lds_image.size() * sizeof(f32x4) + 16);
-    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_lds;
+                 b_pairs = up(ctx->h_pairs.size() * sizeof(f32x4) + 16);
+    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs;
     if (total > ctx->blob_bytes) {
         if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
@@ -736,8 +758,7 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     S.materials = (const MaterialRec*)put(ctx->h_materials, sizeof(ctx->h_materials), b_mat);
     S.textures = (const TextureRec*)put(ctx->h_textures, sizeof(ctx->h_textures), b_tex);
     S.cam = (const CameraRec*)put(&ctx->h_cam, sizeof(ctx->h_cam), b_cam);
-    S.lds_image = (const f32x4*)put(ctx->h_lds_image.data(), ctx->h_lds_image.size() * sizeof(f32x4), b_lds);
-    S.lds_vecs = (int)ctx->h_lds_image.size();
+    S.pairs = (const f32x4*)put(ctx->h_pairs.data(), ctx->h_pairs.size() * sizeof(f32x4), b_pairs);
     S.n_groups = (int)ctx->h_groups.size();
     HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
     ctx->committed = true;
@@ -783,12 +804,13 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
         A.k0 = (uint32_t)(seed & 0xffffffffu); A.k1 = (uint32_t)(seed >> 32);
         A.paths = path_colours ? path_colours : ctx->d_paths;
         A.stats = ctx->d_stats;
+        A.next_batch = ctx->d_next_batch;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_next_batch, 0, sizeof(unsigned long long), st));
         A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
         A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
-        // persistent grid: as many workgroups as stay resident with this scene's LDS image
-        const size_t lds_bytes = (size_t)ctx->scene.lds_vecs * sizeof(f32x4);
+        // persistent grid: as many workgroups as stay resident
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, RENDER_BLOCK, lds_bytes) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, RENDER_BLOCK, 0) != hipSuccess ||
             per_cu < 1)
             per_cu = 1;
         long long waves_wanted = A.n_batches;
@@ -801,7 +823,7 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
             HIP_TRY(ctx, hipEventCreate(&ev1));
             HIP_TRY(ctx, hipEventRecord(ev0, st));
         }
-        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), lds_bytes, st, ctx->scene, A);
+        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, ctx->scene, A);
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->profiling) {
             HIP_TRY(ctx, hipEventRecord(ev1, st));
@@ -876,6 +898,7 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     out->disk_pairs = raw[STAT_PATHS + 4];
     out->sphere_lane_slots = raw[STAT_PATHS + 5];
     out->triangle_lane_slots = raw[STAT_PATHS + 6];
+    for (int i = 0; i < 8; ++i) out->clock_ticks[i] = raw[STAT_PATHS + 7 + i];
     return WRT_OK;
 }
 

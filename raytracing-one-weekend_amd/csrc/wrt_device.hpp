@@ -12,20 +12,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// Build-time variants of the group loops (measured on MI355X, bunny workload,
-// same box: see profiles/): two primitives per trip is +3..17 %; keeping the
-// records in LDS (broadcast ds_read_b128 into VGPRs, with or without the
-// two-register-set pipeline) is 8-13 % slower than scalar loads into SGPRs.
-#ifndef WRT_UNROLL2
-#define WRT_UNROLL2 1
-#endif
-#ifndef WRT_PINGPONG
-#define WRT_PINGPONG 0
-#endif
-#ifndef WRT_USE_LDS
-#define WRT_USE_LDS 0
-#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Wave-uniform read-only data is fetched through the constant address space
 // so that hipcc selects scalar (s_load) instructions and the values arrive
@@ -44,7 +31,7 @@ enum { PURPOSE_JITTER = 0, PURPOSE_LENS = 1, PURPOSE_UNITVEC = 2, PURPOSE_SCHLIC
 
 struct GroupRec {            // 96 bytes, uniform
     int type, first, count, material;
-    int lds_base;            // first f32x4 of this group's records in the LDS image, -1 = not resident
+    int pair_base;           // first f32x4 of this group's component-interleaved pair records
     int pad[3];
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2
     float n[4];              // disk: unit normal
@@ -86,8 +73,7 @@ struct SceneRec {
     const MaterialRec* materials;
     const TextureRec* textures;   // 16 slots
     const CameraRec* cam;
-    const f32x4* lds_image;       // records of the LDS-resident groups, copied to LDS by the render kernel
-    int lds_vecs;
+    const f32x4* pairs;           // sphere and triangle groups again, two primitives per record (group loops)
     float horizon[3], zenith[3];
     int n_groups;
 };
@@ -249,161 +235,236 @@ __device__ __forceinline__ bool disk_hit(const Ray& r, const float c[4], const f
 }
 
 // ---- wave-uniform loops over one group --------------------------------------
-// All 64 lanes walk the same primitives; the primitive records arrive in
-// SGPRs through scalar loads issued one primitive ahead of their use.  Lanes
-// with `active` false ride along.  Lowest index wins equal t (numpy.argmin,
-// sphere_group.py:213, triangle_group.py:399); an earlier group wins equal t
-// (strict <, main.py:144).
-// Record sources for the loops.  Scalar*: wave-uniform scalar loads, the
-// records arrive in SGPRs and feed the VALU as scalar operands (default).
-// Lds*: broadcast reads of the workgroup's LDS image, the records arrive in
-// VGPRs (WRT_USE_LDS=1; kept for comparison).
-struct TriRec { f32x4 a, b; float bz; };     // a = (P0, A.x), b = (A.y, A.z, B.x, B.y), bz = B.z
+// All 64 lanes walk the same primitives, two per step: the records of two
+// neighbouring primitives are stored component-interleaved, arrive in SGPR
+// pairs through scalar loads issued one step ahead of their use, and feed
+// packed FP32 instructions (v_pk_mul_f32 / v_pk_add_f32) whose two halves
+// belong to the two primitives.  A packed instruction takes its SGPR-pair
+// operand at no extra issue cost, where a plain VALU instruction with an SGPR
+// operand issues at little more than half the rate of an all-VGPR one.  Each
+// half is an ordinary IEEE multiply or add, so the results are the ones of
+// the one-primitive functions above.  Lanes with `active` false ride along.
+// Lowest index wins equal t (numpy.argmin, sphere_group.py:213,
+// triangle_group.py:399); an earlier group wins equal t (strict <,
+// main.py:144).  A group with an odd count ends in a pair whose second half
+// repeats the first: the repeat has the same t and so never wins.
+struct SpherePair { f32x2 cx, cy, cz, r2; };                          // 2 x f32x4
+struct TriPair { f32x2 p0x, p0y, p0z, ax, ay, az, bx, by, bz; };      // 5 x f32x4 (last two floats unused)
+enum { SPHERE_PAIR_VECS = 2, TRIANGLE_PAIR_VECS = 5 };
 
-struct ScalarSpheres {
-    const WRT_CONST f32x4* p;
-    __device__ __forceinline__ f32x4 operator[](int j) const { return p[j]; }
-};
-struct LdsSpheres {
-    const f32x4* p;
-    __device__ __forceinline__ f32x4 operator[](int j) const { return p[j]; }
-};
-struct ScalarTriangles {
-    const WRT_CONST f32x4* p;
-    const WRT_CONST float* z;
-    __device__ __forceinline__ TriRec operator[](int j) const { return TriRec{p[2 * j], p[2 * j + 1], z[j]}; }
-};
-struct LdsTriangles {
-    const f32x4* p;
-    const float* z;
-    __device__ __forceinline__ TriRec operator[](int j) const { return TriRec{p[2 * j], p[2 * j + 1], z[j]}; }
-};
+// Scalar loads return out of order, so the only usable wait is "all of them".
+// The loops below therefore keep exactly one record fetch in flight: they wait
+// for everything, issue the fetch of the next record and then spend a whole
+// step of arithmetic on the record that has just arrived.  Two register sets
+// alternate, so no record is ever copied (a scalar move costs a SIMD as much
+// issue time as a packed multiply, and the scalar unit is shared by the four
+// SIMDs of a compute unit).  The fetch one past a group's last record lands in
+// the next group's records or in the padding that ends the array.
+typedef float f32x16a __attribute__((ext_vector_type(16), aligned(16)));
+typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
 
-__device__ __forceinline__ TriTerms triangle_terms(const Ray& r, const TriRec& k) {
-    return triangle_terms(r, k.a.x, k.a.y, k.a.z, k.a.w, k.b.x, k.b.y, k.b.z, k.b.w, k.bz);
+// wait for every scalar load in flight; nothing may be scheduled across
+#define WRT_SCALAR_LOADS_ARRIVED()                 \
+    do {                                           \
+        __builtin_amdgcn_s_waitcnt(0xc07f);        \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+#define WRT_PIN() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ TriPair fetch_triangle_pair(const WRT_CONST f32x4* p) {
+    const f32x16a lo = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
+    const f32x2a hi = *reinterpret_cast<const WRT_CONST f32x2a*>(p + 4);
+    return TriPair{{lo[0], lo[1]},   {lo[2], lo[3]},   {lo[4], lo[5]},   {lo[6], lo[7]},  {lo[8], lo[9]},
+                   {lo[10], lo[11]}, {lo[12], lo[13]}, {lo[14], lo[15]}, {hi[0], hi[1]}};
+}
+struct SphereQuad { SpherePair a, b; };
+__device__ __forceinline__ SphereQuad fetch_sphere_quad(const WRT_CONST f32x4* p) {
+    const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
+    return SphereQuad{SpherePair{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}},
+                      SpherePair{{v[8], v[9]}, {v[10], v[11]}, {v[12], v[13]}, {v[14], v[15]}}};
 }
 
-template <typename Src>
-__device__ __forceinline__ void loop_spheres(const Src sph, int g, int first, int count, bool active,
-                                             const Ray& r, float t_min, float sentinel, Closest& best) {
-    // inactive lanes can never pass the discriminant test
-    const float thr = active ? 0.00001f : __builtin_inff();
-    int j = 0;
-#if WRT_UNROLL2
-    // two spheres per trip: one wait for the loads, one vote
-    if (count >= 2) {
-        f32x4 na = sph[0], nb = sph[1];
-        for (; j + 1 < count; j += 2) {
-            const f32x4 sa = na, sb = nb;
-            const int jn = (j + 3 < count) ? j + 2 : j;
-            na = sph[jn]; nb = sph[jn + 1];
-            float ha, hb;
-            const float da = sphere_discriminant(r, sa.x, sa.y, sa.z, sa.w, ha);
-            const float db = sphere_discriminant(r, sb.x, sb.y, sb.z, sb.w, hb);
-            if (__ballot(fmaxf(da, db) > thr) != 0ull) {
-                const float ta = sphere_root(ha, da, t_min, sentinel);
-                if (active && da > thr && ta < best.t) { best.t = ta; best.group = g; best.prim = first + j; }
-                const float tb = sphere_root(hb, db, t_min, sentinel);
-                if (active && db > thr && tb < best.t) { best.t = tb; best.group = g; best.prim = first + j + 1; }
-            }
-        }
-    }
-#endif
-    if (j < count) {
-        f32x4 next = sph[j];
-        for (; j < count; ++j) {
-            const f32x4 s = next;
-            next = sph[(j + 1 < count) ? j + 1 : j];
+struct Ray2 { f32x2 ox, oy, oz, dx, dy, dz; };                        // each component in both halves
+__device__ __forceinline__ Ray2 both_halves(const Ray& r) {
+    return Ray2{{r.ox, r.ox}, {r.oy, r.oy}, {r.oz, r.oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}};
+}
+
+__device__ __forceinline__ f32x2 sphere_discriminant2(const Ray2& r, const SpherePair& s, f32x2& h) {
+    const f32x2 cox = r.ox - s.cx, coy = r.oy - s.cy, coz = r.oz - s.cz;
+    h = (r.dx * cox + r.dy * coy) + r.dz * coz;
+    const f32x2 c = ((cox * cox + coy * coy) + coz * coz) - s.r2;
+    return h * h - c;
+}
+
+// Candidates of the vote are not evaluated on the spot: a hit is rare for one
+// lane but common for some lane of 64, and the exact evaluation (IEEE square
+// root or division, compares) costs a wavefront more than the arithmetic of
+// the step itself.  Each lane instead notes the primitives it has to look at
+// in a short queue in LDS, in index order, and the wavefront works the queues
+// off together afterwards, each lane fetching its own primitives: a few
+// trips per group instead of one per candidate.
+enum { QUEUE_SLOTS = 8 };
+struct LaneQueue {
+    unsigned* slot;     // slot[k * 64]: k-th queued primitive (index inside the group) of this lane
+    int n;
+};
+__device__ __forceinline__ void push(LaneQueue& q, bool take, int index) {
+    if (take) { q.slot[q.n * 64] = (unsigned)index; ++q.n; }
+}
+// true when some lane's queue cannot take `entries` more: time to work the queues off
+__device__ __forceinline__ bool short_of_room(const LaneQueue& q, int entries) {
+    return __ballot(q.n > QUEUE_SLOTS - entries) != 0ull;
+}
+
+// sphere_group.py:190-213 for the queued spheres of each lane
+__device__ __forceinline__ void drain_spheres(const SceneRec& S, LaneQueue& q, int g, int first, const Ray& r,
+                                              float t_min, float sentinel, Closest& best) {
+    for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
+        if (k < q.n) {
+            const int prim = first + (int)q.slot[k * 64];
+            const f32x4 s = S.sph[prim];
             float h;
             const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
-            if (__ballot(disc > thr) != 0ull) {
-                const float t = sphere_root(h, disc, t_min, sentinel);
-                if (active && disc > thr && t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
-            }
+            const float t = sphere_root(h, disc, t_min, sentinel);
+            if (disc > 0.00001f && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
         }
+    }
+    q.n = 0;
+}
+
+// one vote for two spheres; the lanes that have to look at one note it down
+__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, float thr, const Ray2& r2, LaneQueue& q) {
+    f32x2 h;
+    const f32x2 d = sphere_discriminant2(r2, s, h);
+    if (__ballot(fmaxf(d.x, d.y) > thr) != 0ull) {
+        push(q, d.x > thr, index);
+        push(q, d.y > thr, index + 1);
     }
 }
 
-// Conservative filter for one triangle (1-ulp reciprocal, widened bounds):
-// the returned slack is negative only when the exact evaluation cannot
-// produce a hit closer than t_cap.  One number per pair, so a single compare
-// feeds the wave-level vote.
-__device__ __forceinline__ float triangle_slack(const TriTerms& k, float t_lo, float t_cap) {
-    const float ri = __builtin_amdgcn_rcpf(k.det);
-    const float ua = k.un * ri, va = k.vn * ri, ta = k.tn * ri;
-    const float inside = fminf(fminf(ua, va), 1.00001f - (ua + va)) + 0.00001f;
-    return fminf(fminf(inside, ta - t_lo), t_cap - ta);
-}
-
-// Two triangles at once: shared vote, exact evaluation only when some lane may hit.
-__device__ __forceinline__ void triangle_pair(const TriRec& ra, const TriRec& rb, int g, int prim, bool active,
-                                              const Ray& r, float t_min, float t_max, float t_lo, float t_hi,
-                                              float& t_cap, Closest& best) {
-    const TriTerms ka = triangle_terms(r, ra), kb = triangle_terms(r, rb);
-    const float sa = triangle_slack(ka, t_lo, t_cap), sb = triangle_slack(kb, t_lo, t_cap);
-    if (__ballot(fmaxf(sa, sb) >= 0.0f) != 0ull) {
-        float t;
-        if (triangle_exact(ka, t_min, t_max, t) && active && sa >= 0.0f && t < best.t) {
-            best.t = t; best.group = g; best.prim = prim;
-        }
-        if (triangle_exact(kb, t_min, t_max, t) && active && sb >= 0.0f && t < best.t) {
-            best.t = t; best.group = g; best.prim = prim + 1;
-        }
-        t_cap = active ? fminf(t_hi, best.t * 1.00001f) : -1.0f;
-    }
-}
-
-// `tri[j]` is triangle j of the group.
-template <typename Src>
-__device__ __forceinline__ void loop_triangles(const Src tri, int g, int first, int count, bool active,
-                                               const Ray& r, float t_min, float t_max, Closest& best) {
-    const float t_lo = t_min * 0.99999f, t_hi = t_max * 1.00001f;
-    // inactive lanes get an unreachable cap
-    float t_cap = active ? fminf(t_hi, best.t * 1.00001f) : -1.0f;
+// `records`: the group's sphere pairs, 2 x f32x4 each
+__device__ __forceinline__ void loop_spheres(const SceneRec& S, const WRT_CONST f32x4* records, int g, int first,
+                                             int count, bool active, const Ray& r, float t_min, float sentinel,
+                                             LaneQueue& q, Closest& best) {
+    // inactive lanes can never pass the discriminant test
+    const float thr = active ? 0.00001f : __builtin_inff();
+    const Ray2 r2 = both_halves(r);
+    const int pairs = (count + 1) >> 1;
+    // a repeated last sphere may be queued: same t, never wins
+    SphereQuad A = fetch_sphere_quad(records), B;
     int j = 0;
-#if WRT_UNROLL2
-#if WRT_PINGPONG
-    // Software pipeline with two register sets: the records of the pair after
-    // next are requested before a pair is evaluated.
-    if (count >= 4) {
-        TriRec x0 = tri[0], x1 = tri[1];
-        for (; j + 3 < count; j += 4) {
-            const TriRec y0 = tri[j + 2], y1 = tri[j + 3];
-            __builtin_amdgcn_sched_barrier(0);      // keep the requests above the arithmetic they overlap with
-            triangle_pair(x0, x1, g, first + j, active, r, t_min, t_max, t_lo, t_hi, t_cap, best);
-            const int jx = (j + 5 < count) ? j + 4 : j;
-            x0 = tri[jx]; x1 = tri[jx + 1];
-            __builtin_amdgcn_sched_barrier(0);
-            triangle_pair(y0, y1, g, first + j + 2, active, r, t_min, t_max, t_lo, t_hi, t_cap, best);
+    for (; j + 3 < pairs; j += 4) {
+        WRT_SCALAR_LOADS_ARRIVED();
+        if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+        B = fetch_sphere_quad(records + 4);
+        WRT_PIN();
+        sphere_step(A.a, 2 * j, thr, r2, q);
+        sphere_step(A.b, 2 * j + 2, thr, r2, q);
+        WRT_SCALAR_LOADS_ARRIVED();
+        if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+        A = fetch_sphere_quad(records + 8);
+        WRT_PIN();
+        sphere_step(B.a, 2 * j + 4, thr, r2, q);
+        sphere_step(B.b, 2 * j + 6, thr, r2, q);
+        records += 8;
+    }
+    WRT_SCALAR_LOADS_ARRIVED();
+    if (j < pairs) {                       // up to three pairs left: A holds two of them
+        if (short_of_room(q, 6)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+        B = fetch_sphere_quad(records + 4);
+        sphere_step(A.a, 2 * j, thr, r2, q);
+        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, thr, r2, q);
+        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, thr, r2, q);
+    }
+    drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+}
+
+struct TriTerms2 { f32x2 det, un, vn, tn; };
+__device__ __forceinline__ TriTerms2 triangle_terms2(const Ray2& r, const TriPair& k) {
+    TriTerms2 o;
+    const f32x2 p0 = r.dy * k.bz - r.dz * k.by, p1 = r.dz * k.bx - r.dx * k.bz, p2 = r.dx * k.by - r.dy * k.bx;
+    o.det = (k.ax * p0 + k.ay * p1) + k.az * p2;
+    const f32x2 tx = r.ox - k.p0x, ty = r.oy - k.p0y, tz = r.oz - k.p0z;
+    o.un = (tx * p0 + ty * p1) + tz * p2;
+    const f32x2 q0 = ty * k.az - tz * k.ay, q1 = tz * k.ax - tx * k.az, q2 = tx * k.ay - ty * k.ax;
+    o.vn = (r.dx * q0 + r.dy * q1) + r.dz * q2;
+    o.tn = (k.bx * q0 + k.by * q1) + k.bz * q2;
+    return o;
+}
+
+// Conservative filter for two triangles (1-ulp reciprocal, widened bounds):
+// a slack is negative only when the exact evaluation cannot produce a hit
+// closer than t_cap.  One number per pair of primitives, so a single compare
+// feeds the wave-level vote.
+__device__ __forceinline__ f32x2 triangle_slack2(const TriTerms2& k, float t_lo, float t_cap) {
+    const f32x2 ri = {__builtin_amdgcn_rcpf(k.det.x), __builtin_amdgcn_rcpf(k.det.y)};
+    const f32x2 ua = k.un * ri, va = k.vn * ri, ta = k.tn * ri;
+    const f32x2 w = 1.00001f - (ua + va);
+    const f32x2 inside = f32x2{fminf(fminf(ua.x, va.x), w.x), fminf(fminf(ua.y, va.y), w.y)} + 0.00001f;
+    const f32x2 lo = ta - t_lo, hi = t_cap - ta;
+    return f32x2{fminf(fminf(inside.x, lo.x), hi.x), fminf(fminf(inside.y, lo.y), hi.y)};
+}
+
+struct TriangleWalk { float t_min, t_max, t_lo, t_hi, t_cap; };
+
+// triangle_group.py:302-399 for the queued triangles of each lane
+__device__ __forceinline__ void drain_triangles(const SceneRec& S, LaneQueue& q, int g, int first, bool active,
+                                                const Ray& r, TriangleWalk& w, Closest& best) {
+    for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
+        if (k < q.n) {
+            const int prim = first + (int)q.slot[k * 64];
+            const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
+            const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
+            float t;
+            if (triangle_exact(terms, w.t_min, w.t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
         }
     }
-#endif
-    if (j + 1 < count) {
-        TriRec n0 = tri[j], n1 = tri[j + 1];
-        for (; j + 1 < count; j += 2) {
-            const TriRec a = n0, b = n1;
-            const int jn = (j + 3 < count) ? j + 2 : j;
-            n0 = tri[jn]; n1 = tri[jn + 1];
-            triangle_pair(a, b, g, first + j, active, r, t_min, t_max, t_lo, t_hi, t_cap, best);
-        }
+    q.n = 0;
+    // inactive lanes keep an unreachable cap
+    w.t_cap = active ? fminf(w.t_hi, best.t * 1.00001f) : -__builtin_inff();
+}
+
+// one vote for two triangles; the lanes that have to look at one note it down
+__device__ __forceinline__ void triangle_step(const TriPair& rec, int index, const Ray2& r2, const TriangleWalk& w,
+                                              LaneQueue& q) {
+    const TriTerms2 k = triangle_terms2(r2, rec);
+    const f32x2 slack = triangle_slack2(k, w.t_lo, w.t_cap);
+    if (__ballot(fmaxf(slack.x, slack.y) >= 0.0f) != 0ull) {
+        push(q, slack.x >= 0.0f, index);
+        push(q, slack.y >= 0.0f, index + 1);
     }
-#endif
-    if (j < count) {
-        TriRec next = tri[j];
-        for (; j < count; ++j) {
-            const TriRec cur = next;
-            next = tri[(j + 1 < count) ? j + 1 : j];
-            const TriTerms k = triangle_terms(r, cur);
-            const float slack = triangle_slack(k, t_lo, t_cap);
-            if (__ballot(slack >= 0.0f) != 0ull) {
-                float t;
-                if (triangle_exact(k, t_min, t_max, t) && active && slack >= 0.0f && t < best.t) {
-                    best.t = t; best.group = g; best.prim = first + j;
-                    t_cap = fminf(t_hi, t * 1.00001f);
-                }
-            }
-        }
+}
+
+// `records`: the group's triangle pairs, 5 x f32x4 each
+__device__ __forceinline__ void loop_triangles(const SceneRec& S, const WRT_CONST f32x4* records, int g, int first,
+                                               int count, bool active, const Ray& r, float t_min, float t_max,
+                                               LaneQueue& q, Closest& best) {
+    TriangleWalk w = {t_min, t_max, t_min * 0.99999f, t_max * 1.00001f, 0.0f};
+    w.t_cap = active ? fminf(w.t_hi, best.t * 1.00001f) : -__builtin_inff();
+    const Ray2 r2 = both_halves(r);
+    const int pairs = (count + 1) >> 1;
+    // a repeated last triangle may be queued: same t, never wins
+    TriPair A = fetch_triangle_pair(records), B;
+    int j = 0;
+    for (; j + 1 < pairs; j += 2) {
+        WRT_SCALAR_LOADS_ARRIVED();
+        if (short_of_room(q, 2)) drain_triangles(S, q, g, first, active, r, w, best);
+        B = fetch_triangle_pair(records + 5);
+        WRT_PIN();
+        triangle_step(A, 2 * j, r2, w, q);
+        WRT_SCALAR_LOADS_ARRIVED();
+        if (short_of_room(q, 2)) drain_triangles(S, q, g, first, active, r, w, best);
+        A = fetch_triangle_pair(records + 10);
+        WRT_PIN();
+        triangle_step(B, 2 * j + 2, r2, w, q);
+        records += 10;
     }
+    WRT_SCALAR_LOADS_ARRIVED();
+    if (j < pairs) {
+        if (short_of_room(q, 2)) drain_triangles(S, q, g, first, active, r, w, best);
+        triangle_step(A, 2 * j, r2, w, q);
+    }
+    drain_triangles(S, q, g, first, active, r, w, best);
 }
 
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
@@ -423,8 +484,8 @@ __device__ __forceinline__ void lane_spheres(const SceneRec& S, int g, int first
 __device__ __forceinline__ void lane_triangles(const SceneRec& S, int g, int first, int count, const Ray& r,
                                                float t_min, float t_max, Closest& best) {
     for (int j = 0; j < count; ++j) {
-        const TriRec rec = {S.tri[2 * (first + j)], S.tri[2 * (first + j) + 1], S.tri_bz[first + j]};
-        const TriTerms k = triangle_terms(r, rec);
+        const f32x4 a = S.tri[2 * (first + j)], b = S.tri[2 * (first + j) + 1];
+        const TriTerms k = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[first + j]);
         float t;
         if (triangle_exact(k, t_min, t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
     }
@@ -434,7 +495,7 @@ __device__ __forceinline__ void lane_triangles(const SceneRec& S, int g, int fir
 // groups together (stage entry point wrt_intersect).  Every lane of the
 // wavefront must call this; `live` masks lanes without a ray.
 __device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int g_end, bool live, const Ray& r,
-                                            float t_min, float t_max, Closest& best, PairCounts& pc) {
+                                            float t_min, float t_max, LaneQueue& q, Closest& best, PairCounts& pc) {
     const float sentinel = t_max + 1.0f;
     best.t = sentinel; best.group = -1; best.prim = -1;
     const WRT_CONST GroupRec* groups = as_uniform(S.groups);
@@ -446,7 +507,8 @@ __device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int 
         if (type == GROUP_SPHERES) {
             pc.sphere += (unsigned long long)n_live * (unsigned)count;
             pc.sphere_slots += 64ull * (unsigned)count;
-            loop_spheres(ScalarSpheres{as_uniform(S.sph) + first}, g, first, count, live, r, t_min, sentinel, best);
+            loop_spheres(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, live, r, t_min, sentinel, q,
+                         best);
         } else if (type == GROUP_TRIANGLES) {
             const bool pass = live && cull_pass(r, groups[g].c[0], groups[g].c[1], groups[g].c[2], groups[g].c[3]);
             const unsigned long long pass_mask = __ballot(pass);
@@ -454,8 +516,8 @@ __device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int 
             if (pass_mask == 0ull) continue;
             pc.triangle += (unsigned long long)__popcll(pass_mask) * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
-            loop_triangles(ScalarTriangles{as_uniform(S.tri) + 2 * first, as_uniform(S.tri_bz) + first}, g, first, count,
-                           pass, r, t_min, t_max, best);
+            loop_triangles(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, pass, r, t_min, t_max, q,
+                           best);
         } else {
             pc.disk += n_live;
             float c[4], n[4];

@@ -42,6 +42,7 @@ class WrtStats(ctypes.Structure):
         ("paths", ctypes.c_uint64), ("sphere_pairs", ctypes.c_uint64), ("triangle_pairs", ctypes.c_uint64),
         ("cull_tests", ctypes.c_uint64), ("disk_pairs", ctypes.c_uint64),
         ("sphere_lane_slots", ctypes.c_uint64), ("triangle_lane_slots", ctypes.c_uint64),
+        ("clock_ticks", ctypes.c_uint64 * 8),
     ]
 
 
@@ -324,7 +325,8 @@ class Context:
         return dict(rays_per_bounce=np.array(list(s.rays_per_bounce), dtype=np.int64), paths=int(s.paths),
                     sphere_pairs=int(s.sphere_pairs), triangle_pairs=int(s.triangle_pairs),
                     cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs),
-                    sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots))
+                    sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots),
+                    clock_ticks=np.array(list(s.clock_ticks), dtype=np.int64))
 
 
 _contexts = {}

@@ -36,6 +36,19 @@ __global__ void k(float* out, long long* cyc, int iters, float seed) {
                 if (MODE == 16) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
                 if (MODE == 17) asm volatile("v_mul_f32 %0, 0x3f800054, %0" : "+v"(a[i]));
                 if (MODE == 18) asm volatile("v_mul_f32 %0, 2.0, %0" : "+v"(a[i]));
+                if (MODE == 19) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "s"(pm));
+                if (MODE == 20) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "s"(pm), "v"(pc));
+                if (MODE == 21) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "v"(pm));
+                if (MODE == 22) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "s"(pm));
+                if (MODE == 23) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p[i]) : "v"(pc), "s"(pm));
+                if (MODE == 24) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(p[i]) : "v"(pc), "s"(pm));
+                if (MODE == 26) asm volatile("v_pk_mul_f32 %0, %0, %1\n\ts_mov_b32 s20, s21" : "+v"(p[i]) : "s"(pm) : "s20");
+                if (MODE == 27) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_mov_b32 s20, s21" : "+v"(a[i]) : "v"(m), "v"(c) : "s20");
+                if (MODE == 28) asm volatile("v_pk_mul_f32 %0, %0, %1\n\ts_mov_b32 s20, s21\n\ts_mov_b32 s22, s23" : "+v"(p[i]) : "s"(pm) : "s20", "s22");
+                if (MODE == 29) asm volatile("s_mov_b32 s20, s21\n\ts_mov_b32 s22, s23" : : : "s20", "s22");
+                if (MODE == 30) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[(i + 3) & 7]), "s"(pm));
+                if (MODE == 31) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[(i + 7) & 7]), "s"(pm));
+                if (MODE == 25) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "v"(pm));
             }
         }
     }
@@ -69,6 +82,10 @@ int main() {
     run<4>("v_rcp_f32"); run<5>("v_add_f32 sgpr"); run<6>("v_min3_f32"); run<7>("v_cmp_lt_f32");
     run<8>("v_mul_f32 sgpr"); run<9>("v_fma_f32 sgpr"); run<10>("v_add_f32 vgpr"); run<11>("v_sub_f32 sgpr"); run<12>("v_fma 2src");
     run<13>("v_mul dpp ror3"); run<14>("v_mov dpp ror1"); run<15>("v_mov sgpr"); run<16>("v_max_f32"); run<17>("v_mul literal"); run<18>("v_mul inline2.0");
+    run<19>("pk_mul sgpr"); run<20>("pk_fma sgpr"); run<21>("pk_mul bcast"); run<22>("pk_add sgpr");
+    run<23>("pk_mul s+bcast"); run<24>("pk_fma s+b+neg"); run<25>("pk_add neg");
+    run<26>("pk_mul+1smov"); run<27>("fma+1smov"); run<28>("pk_mul+2smov"); run<29>("2 smov only");
+    run<30>("pk_mul dist3"); run<31>("pk_mul dep chain");
     run<0>("v_fma_f32 again");
     return 0;
 }
