@@ -247,7 +247,7 @@ __device__ __forceinline__ bool disk_hit(const Ray& r, const float c[4], const f
 // Lowest index wins equal t (numpy.argmin, sphere_group.py:213,
 // triangle_group.py:399); an earlier group wins equal t (strict <,
 // main.py:144).  A group with an odd count ends in a pair whose second half
-// repeats the first: the repeat has the same t and so never wins.
+// repeats the first.
 struct SpherePair { f32x2 cx, cy, cz, r2; };                          // 2 x f32x4
 struct TriPair { f32x2 p0x, p0y, p0z, ax, ay, az, bx, by, bz; };      // 5 x f32x4 (last two floats unused)
 enum { SPHERE_PAIR_VECS = 2, TRIANGLE_PAIR_VECS = 5 };
@@ -333,12 +333,14 @@ __device__ __forceinline__ void drain_spheres(const SceneRec& S, LaneQueue& q, i
 }
 
 // one vote for two spheres; the lanes that have to look at one note it down
-__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, float thr, const Ray2& r2, LaneQueue& q) {
+// (index + 1 == count: the second half repeats the group's last sphere and is left out)
+__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int count, float thr, const Ray2& r2,
+                                            LaneQueue& q) {
     f32x2 h;
     const f32x2 d = sphere_discriminant2(r2, s, h);
     if (__ballot(fmaxf(d.x, d.y) > thr) != 0ull) {
         push(q, d.x > thr, index);
-        push(q, d.y > thr, index + 1);
+        push(q, d.y > thr && index + 1 < count, index + 1);
     }
 }
 
@@ -350,7 +352,6 @@ __device__ __forceinline__ void loop_spheres(const SceneRec& S, const WRT_CONST 
     const float thr = active ? 0.00001f : __builtin_inff();
     const Ray2 r2 = both_halves(r);
     const int pairs = (count + 1) >> 1;
-    // a repeated last sphere may be queued: same t, never wins
     SphereQuad A = fetch_sphere_quad(records), B;
     int j = 0;
     for (; j + 3 < pairs; j += 4) {
@@ -358,23 +359,23 @@ __device__ __forceinline__ void loop_spheres(const SceneRec& S, const WRT_CONST 
         if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
         WRT_PIN();
-        sphere_step(A.a, 2 * j, thr, r2, q);
-        sphere_step(A.b, 2 * j + 2, thr, r2, q);
+        sphere_step(A.a, 2 * j, count, thr, r2, q);
+        sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
         WRT_SCALAR_LOADS_ARRIVED();
         if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         A = fetch_sphere_quad(records + 8);
         WRT_PIN();
-        sphere_step(B.a, 2 * j + 4, thr, r2, q);
-        sphere_step(B.b, 2 * j + 6, thr, r2, q);
+        sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
+        sphere_step(B.b, 2 * j + 6, count, thr, r2, q);
         records += 8;
     }
     WRT_SCALAR_LOADS_ARRIVED();
     if (j < pairs) {                       // up to three pairs left: A holds two of them
         if (short_of_room(q, 6)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
-        sphere_step(A.a, 2 * j, thr, r2, q);
-        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, thr, r2, q);
-        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, thr, r2, q);
+        sphere_step(A.a, 2 * j, count, thr, r2, q);
+        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
+        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
     }
     drain_spheres(S, q, g, first, r, t_min, sentinel, best);
 }
@@ -425,13 +426,14 @@ __device__ __forceinline__ void drain_triangles(const SceneRec& S, LaneQueue& q,
 }
 
 // one vote for two triangles; the lanes that have to look at one note it down
-__device__ __forceinline__ void triangle_step(const TriPair& rec, int index, const Ray2& r2, const TriangleWalk& w,
-                                              LaneQueue& q) {
+// (index + 1 == count: the second half repeats the group's last triangle and is left out)
+__device__ __forceinline__ void triangle_step(const TriPair& rec, int index, int count, const Ray2& r2,
+                                              const TriangleWalk& w, LaneQueue& q) {
     const TriTerms2 k = triangle_terms2(r2, rec);
     const f32x2 slack = triangle_slack2(k, w.t_lo, w.t_cap);
     if (__ballot(fmaxf(slack.x, slack.y) >= 0.0f) != 0ull) {
         push(q, slack.x >= 0.0f, index);
-        push(q, slack.y >= 0.0f, index + 1);
+        push(q, slack.y >= 0.0f && index + 1 < count, index + 1);
     }
 }
 
@@ -443,7 +445,6 @@ __device__ __forceinline__ void loop_triangles(const SceneRec& S, const WRT_CONS
     w.t_cap = active ? fminf(w.t_hi, best.t * 1.00001f) : -__builtin_inff();
     const Ray2 r2 = both_halves(r);
     const int pairs = (count + 1) >> 1;
-    // a repeated last triangle may be queued: same t, never wins
     TriPair A = fetch_triangle_pair(records), B;
     int j = 0;
     for (; j + 1 < pairs; j += 2) {
@@ -451,18 +452,18 @@ __device__ __forceinline__ void loop_triangles(const SceneRec& S, const WRT_CONS
         if (short_of_room(q, 2)) drain_triangles(S, q, g, first, active, r, w, best);
         B = fetch_triangle_pair(records + 5);
         WRT_PIN();
-        triangle_step(A, 2 * j, r2, w, q);
+        triangle_step(A, 2 * j, count, r2, w, q);
         WRT_SCALAR_LOADS_ARRIVED();
         if (short_of_room(q, 2)) drain_triangles(S, q, g, first, active, r, w, best);
         A = fetch_triangle_pair(records + 10);
         WRT_PIN();
-        triangle_step(B, 2 * j + 2, r2, w, q);
+        triangle_step(B, 2 * j + 2, count, r2, w, q);
         records += 10;
     }
     WRT_SCALAR_LOADS_ARRIVED();
     if (j < pairs) {
         if (short_of_room(q, 2)) drain_triangles(S, q, g, first, active, r, w, best);
-        triangle_step(A, 2 * j, r2, w, q);
+        triangle_step(A, 2 * j, count, r2, w, q);
     }
     drain_triangles(S, q, g, first, active, r, w, best);
 }

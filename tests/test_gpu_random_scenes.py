@@ -135,3 +135,64 @@ def test_intersect_entry_point_on_random_scene():
     for k in ("mat", "back", "group", "prim"):
         assert np.array_equal(got[k][hit], want[k][hit]), k
     ctx.close()
+
+
+def stacked_scene(n_spheres, n_triangles):
+    """Concentric spheres and a deck of parallel triangles: every ray through the middle is a
+    candidate for dozens of primitives of one group, far more than a lane's queue holds."""
+    materials = {0: dict(kind="diffuse", colour=np.array([0.7, 0.6, 0.5], np.single)),
+                 1: dict(kind="dielectric", ior=1.5), 2: dict(kind="metal", colour=np.array([0.9, 0.9, 0.9], np.single),
+                                                             fuzziness=0.0)}
+    radii = np.linspace(0.2, 1.4, n_spheres).astype(np.single)[::-1].copy()      # outermost first
+    spheres = dict(type="spheres", centres=np.tile(np.array([[-1.5, 1.0, 0.0]], np.single), (n_spheres, 1)),
+                   radii=radii, materials=(np.arange(n_spheres) % 3).astype(np.ubyte))
+    z = np.linspace(-1.0, 1.0, n_triangles).astype(np.single)
+    p0 = np.stack([np.full(n_triangles, 0.5, np.single), np.full(n_triangles, 0.0, np.single), z], axis=1)
+    A = np.tile(np.array([[2.0, 0.0, 0.0]], np.single), (n_triangles, 1))
+    B = np.tile(np.array([[1.0, 2.0, 0.0]], np.single), (n_triangles, 1))
+    nrm = np.tile(np.array([[0.0, 0.0, 1.0]], np.single), (n_triangles, 1))
+    uv = np.zeros((n_triangles, 2), np.single)
+    pts = np.concatenate([p0, p0 + A, p0 + B])
+    bc = np.mean(pts, axis=0).astype(np.single)
+    br = np.single(np.max(np.linalg.norm(pts - bc, axis=1)) * 1.01)
+    tris = dict(type="triangles", pt0=p0, A=A, B=B, n0=nrm, n1=nrm, n2=nrm, uv0=uv, uv1=uv, uv2=uv, material_id=1,
+                bounds_centre=bc, bounds_radius=br)
+    ground = dict(type="spheres", centres=np.array([[0, -500.0, 0]], np.single), radii=np.array([500.0], np.single),
+                  materials=np.array([0], np.ubyte))
+    cam = numpy_path.camera_basis(np.array([0.3, 1.2, 6.0]), np.array([0.0, 1.0, 0.0]), 6.0, 0.0, 1.6, 40.0)
+    sky = dict(horizon=np.array([1, 1, 1], np.single), zenith=np.array([0.5, 0.7, 1.0], np.single))
+    return dict(camera=cam, groups=[ground, spheres, tris], materials=materials, sky=sky)
+
+
+@pytest.mark.parametrize("n_spheres,n_triangles", [(37, 41), (64, 100), (9, 9)])
+def test_more_candidates_than_queue_slots(n_spheres, n_triangles):
+    from weekend_raytracer import _native, main
+    scene = stacked_scene(n_spheres, n_triangles)
+    rng = np.random.default_rng(n_spheres)
+    # rays along +-z through the deck and through the spheres' common centre, plus random ones
+    n = 4096
+    o = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(0.1, 2.0, n), np.where(rng.random(n) < 0.5, -5.0, 5.0)],
+                 axis=1).astype(np.single)
+    target = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(0.1, 2.0, n), np.zeros(n)], axis=1)
+    d = target - o
+    d = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.single)
+    ctx = _native.Context(0)
+    ctx.upload(scene)
+    got = ctx.intersect(-1, o, d, 0.001, 1000.0)
+    ctx.close()
+    want = numpy_path.closest_hit(scene["groups"], o, d)
+    assert np.array_equal(got["hit"], want["hit"])
+    hit = want["hit"]
+    assert hit.mean() > 0.5
+    assert np.array_equal(got["t"][hit], want["t"][hit].astype(np.single))
+    for k in ("group", "prim", "mat", "back"):
+        assert np.array_equal(got[k][hit], want[k][hit]), k
+    # and through the bounce kernel (glass deck: many refractions in a row)
+    w, h, s, b = 40, 25, 2, 12
+    ref = numpy_path.render(scene, w, h, s, b, seed=5)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    out = main.render_frame(objs, w, h, s, b, seed=5, want_paths=True)
+    same = np.all(out["path_colours"] == ref["path_colours"], axis=1)
+    assert same.mean() >= 0.995, same.mean()
+    assert (out["segments"] == ref["segments"]).mean() >= 0.995
