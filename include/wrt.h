@@ -87,8 +87,12 @@ typedef struct wrt_stats {
     /* clock tallies of the bounce kernel, zero unless the library was built with
        -DWRT_TIMING=1 (shader clock ticks, 100 MHz): [0] sum of the wavefronts' lifetimes,
        [1] longest lifetime, [2] in triangle loops, [3] in sphere loops, [4] shading,
-       [5] refilling lanes, [6] per-lane group walk, [7] group loops run */
+       [5] refilling lanes, [6] per-lane group walk, [7] working candidate queues off
+       (part of [2] and [3]) */
     uint64_t clock_ticks[8];
+    /* (ray, triangle) pairs of the large groups that went through the full evaluation;
+       the others were rejected by the bounding-sphere test (see wrt_set_triangle_reject) */
+    uint64_t triangle_evaluations;
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -157,6 +161,13 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
 /* image = sqrt(accum / spp_total)  (main.py:219-220); n_values = width*height*3 */
 int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total,
                  float* image, void* stream);
+
+/* No counterpart in the reference, which evaluates triangle_group.py:289-395 in full
+   for every (ray, triangle) pair.  on = 1 (default): in groups of more than 8 triangles
+   every pair first meets a conservative bounding-sphere test of that one triangle and
+   only the survivors get the full evaluation; results are the same bit for bit.
+   on = 0: the full evaluation for every pair.  Takes effect with the next render. */
+int wrt_set_triangle_reject(wrt_ctx* ctx, int on);
 
 int wrt_stats_reset(wrt_ctx* ctx, void* stream);
 /* synchronises `stream`, then copies the statistics out */

@@ -89,7 +89,7 @@ __device__ __forceinline__ unsigned long long wave_sum_small(bool take, int coun
 __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const SceneRec S, const RenderArgs A) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     const unsigned lane = threadIdx.x & 63u;
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0};
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0};
     // the batch this wave is handing out to its lanes and how many of its 64 paths are gone
     long long batch = 0;
     unsigned batch_used = 64;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     int bounce = 0;
     Ray ray = {0, 0, 0, 0, 0, 1};
     float cr = 1, cg = 1, cb = 1;
-    PairCounts pc = {0, 0, 0, 0, 0, 0};
+    PairCounts pc = {0, 0, 0, 0, 0, 0, 0};
     // slot of a path in the output, ray-id order r = (x*H + y)*S + s (main.py:102-104)
     auto out_slot = [&](const PathKey& k) {
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
@@ -269,11 +269,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         }
         const bool mine = (state == LANE_PARKED) && (g == run_g);
         since = WRT_CLOCK();
-        ticks[7] += WRT_TIMING;
         if (type == GROUP_TRIANGLES) {
             pc.triangle += (unsigned long long)run_n * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
-            loop_triangles(S, records, run_g, first, count, mine, ray, A.t_min, A.t_max, queue, best);
+            const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach);
+            if (S.prefilter && __ballot(!k.usable) == 0ull)
+                loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count, k,
+                                         ray, A.t_min, A.t_max, queue, best, pc.triangle_exact);
+            else
+                loop_triangles(S, records, run_g, first, count, mine, ray, A.t_min, A.t_max, queue, best);
             WRT_TALLY(2, since);
         } else {
             pc.sphere += (unsigned long long)run_n * (unsigned)count;
@@ -291,8 +295,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         if (pc.disk) atomicAdd(&A.stats[STAT_PATHS + 4], pc.disk);
         if (pc.sphere_slots) atomicAdd(&A.stats[STAT_PATHS + 5], pc.sphere_slots);
         if (pc.triangle_slots) atomicAdd(&A.stats[STAT_PATHS + 6], pc.triangle_slots);
+        if (pc.triangle_exact) atomicAdd(&A.stats[STAT_PATHS + 15], pc.triangle_exact);
 #if WRT_TIMING
         ticks[0] = ticks[1] = WRT_CLOCK() - born;
+        ticks[7] = queue.drain_ticks;
         for (int i = 0; i < 8; ++i) {
             if (i == 1) atomicMax(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
             else atomicAdd(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
@@ -369,10 +375,10 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, 
         ray.dx = dirs[i * 3]; ray.dy = dirs[i * 3 + 1]; ray.dz = dirs[i * 3 + 2];
     }
     Closest best;
-    PairCounts pc = {0, 0, 0, 0, 0, 0};
+    PairCounts pc = {0, 0, 0, 0, 0, 0, 0};
     const int g0 = group < 0 ? 0 : group, g1 = group < 0 ? S.n_groups : group + 1;
     __shared__ unsigned queue_slots[256 / 64][QUEUE_SLOTS][64];
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0};
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0, 0};
     closest_hit(S, g0, g1, live, ray, t_min, t_max, queue, best, pc);
     if (!live) return;
     const bool hit = best.t < t_max;
@@ -438,6 +444,8 @@ struct wrt_ctx {
     std::vector<f32x4> h_tri_shade;
     std::vector<GroupRec> h_groups;
     std::vector<f32x4> h_pairs;
+    std::vector<f32x4> h_bounds;
+    int triangle_reject = 1;
     MaterialRec h_materials[WRT_MAX_MATERIALS];
     float* d_textures[WRT_MAX_TEXTURES] = {nullptr};
     TextureRec h_textures[WRT_MAX_TEXTURES];
@@ -488,6 +496,7 @@ static void reset_scene(wrt_ctx* ctx) {
     ctx->h_tri.clear(); ctx->h_tri_bz.clear(); ctx->h_tri_shade.clear(); ctx->h_groups.clear();
     std::memset(ctx->h_materials, 0, sizeof(ctx->h_materials));
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
+    ctx->scene.prefilter = ctx->triangle_reject;
     std::memset(&ctx->h_cam, 0, sizeof(ctx->h_cam));
     ctx->scene.horizon[0] = ctx->scene.horizon[1] = ctx->scene.horizon[2] = 1.0f;
     ctx->scene.zenith[0] = 0.5f; ctx->scene.zenith[1] = 0.7f; ctx->scene.zenith[2] = 1.0f;
@@ -694,6 +703,81 @@ int wrt_set_sky(wrt_ctx* ctx, const float horizon[3], const float zenith[3]) {
     return WRT_OK;
 }
 
+// Smallest sphere around the corners of each triangle of the large groups and B x A, two
+// triangles per record, padded to whole fours with the group's last triangle; the group's
+// largest edge component and largest coordinate for the error bounds of the reject test.
+static void build_bounds(wrt_ctx* ctx) {
+    ctx->h_bounds.clear();
+    for (GroupRec& g : ctx->h_groups) {
+        g.bound_base = (int)ctx->h_bounds.size();
+        g.edge_max = 0.0f; g.reach = 0.0f;
+        if (g.type != GROUP_TRIANGLES) continue;
+        const int padded = (g.count + 3) & ~3;
+        std::vector<float> cx(padded), cy(padded), cz(padded), rr(padded), nx(padded), ny(padded), nz(padded);
+        double edge_max = 0.0, reach = 0.0;
+        for (int j = 0; j < g.count; ++j) {
+            const size_t i = (size_t)g.first + j;
+            const f32x4 r0 = ctx->h_tri[2 * i], r1 = ctx->h_tri[2 * i + 1];
+            const double P[3] = {r0.x, r0.y, r0.z}, A[3] = {r0.w, r1.x, r1.y}, B[3] = {r1.z, r1.w, ctx->h_tri_bz[i]};
+            // the corners as the reference's arithmetic sees them: P0, P0 + A, P0 + B in exact arithmetic
+            double V[3][3];
+            for (int a = 0; a < 3; ++a) { V[0][a] = P[a]; V[1][a] = P[a] + A[a]; V[2][a] = P[a] + B[a]; }
+            auto dist2 = [](const double* p, const double* q) {
+                return (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]);
+            };
+            // longest edge first: its midpoint sphere holds the triangle unless the opposite angle is acute
+            int e0 = 0, e1 = 1, opp = 2;
+            double longest = dist2(V[0], V[1]);
+            if (dist2(V[1], V[2]) > longest) { longest = dist2(V[1], V[2]); e0 = 1; e1 = 2; opp = 0; }
+            if (dist2(V[2], V[0]) > longest) { longest = dist2(V[2], V[0]); e0 = 2; e1 = 0; opp = 1; }
+            double c[3];
+            for (int a = 0; a < 3; ++a) c[a] = 0.5 * (V[e0][a] + V[e1][a]);
+            if (dist2(c, V[opp]) > 0.25 * longest) {
+                // acute: circumcentre = P0 + (|B|^2 (A x B) x A + |A|^2 B x (A x B)) / (2 |A x B|^2)
+                const double n[3] = {A[1] * B[2] - A[2] * B[1], A[2] * B[0] - A[0] * B[2], A[0] * B[1] - A[1] * B[0]};
+                const double n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+                const double a2 = A[0] * A[0] + A[1] * A[1] + A[2] * A[2], b2 = B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
+                if (n2 > 0.0) {
+                    const double nxA[3] = {n[1] * A[2] - n[2] * A[1], n[2] * A[0] - n[0] * A[2], n[0] * A[1] - n[1] * A[0]};
+                    const double Bxn[3] = {B[1] * n[2] - B[2] * n[1], B[2] * n[0] - B[0] * n[2], B[0] * n[1] - B[1] * n[0]};
+                    for (int a = 0; a < 3; ++a) c[a] = P[a] + (b2 * nxA[a] + a2 * Bxn[a]) / (2.0 * n2);
+                }
+            }
+            const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
+            const double cd[3] = {cf[0], cf[1], cf[2]};
+            double r2 = 0.0;
+            for (int k = 0; k < 3; ++k) r2 = std::max(r2, dist2(cd, V[k]));
+            double m = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                m = std::max(m, std::max(std::fabs(A[a]), std::fabs(B[a])));
+                for (int k = 0; k < 3; ++k) reach = std::max(reach, std::fabs(V[k][a]));
+                reach = std::max(reach, std::fabs(cd[a]));
+            }
+            edge_max = std::max(edge_max, m);
+            cx[j] = cf[0]; cy[j] = cf[1]; cz[j] = cf[2];
+            rr[j] = (float)std::sqrt(r2);                      // widened below, once the group's edge_max is known
+            nx[j] = (float)(B[1] * A[2] - B[2] * A[1]);
+            ny[j] = (float)(B[2] * A[0] - B[0] * A[2]);
+            nz[j] = (float)(B[0] * A[1] - B[1] * A[0]);
+        }
+        for (int j = g.count; j < padded; ++j) {
+            cx[j] = cx[g.count - 1]; cy[j] = cy[g.count - 1]; cz[j] = cz[g.count - 1]; rr[j] = rr[g.count - 1];
+            nx[j] = nx[g.count - 1]; ny[j] = ny[g.count - 1]; nz[j] = nz[g.count - 1];
+        }
+        g.edge_max = std::nextafter((float)edge_max, INFINITY);
+        g.reach = std::nextafter((float)reach, INFINITY);
+        for (int j = 0; j < padded; ++j)   // rounding of the radius itself and the 9e-7 M term of the bound
+            rr[j] = std::nextafter((float)((double)rr[j] * (1.0 + 1e-6) + 1e-6 * edge_max), INFINITY);
+        for (int j = 0; j < padded; j += 2) {
+            ctx->h_bounds.push_back(f32x4{cx[j], cx[j + 1], cy[j], cy[j + 1]});
+            ctx->h_bounds.push_back(f32x4{cz[j], cz[j + 1], rr[j], rr[j + 1]});
+            ctx->h_bounds.push_back(f32x4{nx[j], nx[j + 1], ny[j], ny[j + 1]});
+            ctx->h_bounds.push_back(f32x4{nz[j], nz[j + 1], 0.0f, 0.0f});
+        }
+    }
+    for (int i = 0; i < 8; ++i) ctx->h_bounds.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+}
+
 int wrt_scene_commit(wrt_ctx* ctx) {
     if (int r = bind(ctx)) return r;
     for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
@@ -725,6 +809,7 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     }
     // the loops fetch one step past a group's end: keep that read inside the array
     for (int i = 0; i < 8; ++i) ctx->h_pairs.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+    build_bounds(ctx);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_sph = up(ctx->h_sph.size() * sizeof(f32x4) + 16), b_rad = up(ctx->h_sph_radius.size() * 4 + 16),
                  b_smat = up(ctx->h_sph_material.size() + 16), b_tri = up(ctx->h_tri.size() * sizeof(f32x4) + 16),
@@ -732,8 +817,9 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                  b_shade = up(ctx->h_tri_shade.size() * sizeof(f32x4) + 16),
                  b_grp = up(ctx->h_groups.size() * sizeof(GroupRec) + 16), b_mat = up(sizeof(ctx->h_materials)),
                  b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam)),
-                 b_pairs = up(ctx->h_pairs.size() * sizeof(f32x4) + 16);
-    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs;
+                 b_pairs = up(ctx->h_pairs.size() * sizeof(f32x4) + 16),
+                 b_bounds = up(ctx->h_bounds.size() * sizeof(f32x4) + 16);
+    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs + b_bounds;
     if (total > ctx->blob_bytes) {
         if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
@@ -759,6 +845,7 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     S.textures = (const TextureRec*)put(ctx->h_textures, sizeof(ctx->h_textures), b_tex);
     S.cam = (const CameraRec*)put(&ctx->h_cam, sizeof(ctx->h_cam), b_cam);
     S.pairs = (const f32x4*)put(ctx->h_pairs.data(), ctx->h_pairs.size() * sizeof(f32x4), b_pairs);
+    S.bounds = (const f32x4*)put(ctx->h_bounds.data(), ctx->h_bounds.size() * sizeof(f32x4), b_bounds);
     S.n_groups = (int)ctx->h_groups.size();
     HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
     ctx->committed = true;
@@ -870,6 +957,13 @@ int wrt_profile_read(wrt_ctx* ctx, double* kernel_ms, int* launches) {
     return WRT_OK;
 }
 
+int wrt_set_triangle_reject(wrt_ctx* ctx, int on) {
+    if (int r = bind(ctx)) return r;
+    ctx->triangle_reject = on ? 1 : 0;
+    ctx->scene.prefilter = ctx->triangle_reject;
+    return WRT_OK;
+}
+
 int wrt_stats_reset(wrt_ctx* ctx, void* stream) {
     if (int r = bind(ctx)) return r;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(wrt_stats), (hipStream_t)stream));
@@ -899,6 +993,7 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     out->sphere_lane_slots = raw[STAT_PATHS + 5];
     out->triangle_lane_slots = raw[STAT_PATHS + 6];
     for (int i = 0; i < 8; ++i) out->clock_ticks[i] = raw[STAT_PATHS + 7 + i];
+    out->triangle_evaluations = raw[STAT_PATHS + 15];
     return WRT_OK;
 }
 

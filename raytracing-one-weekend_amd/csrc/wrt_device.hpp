@@ -32,7 +32,9 @@ enum { PURPOSE_JITTER = 0, PURPOSE_LENS = 1, PURPOSE_UNITVEC = 2, PURPOSE_SCHLIC
 struct GroupRec {            // 96 bytes, uniform
     int type, first, count, material;
     int pair_base;           // first f32x4 of this group's component-interleaved pair records
-    int pad[3];
+    int bound_base;          // triangles: first f32x4 of the per-triangle bounding records (two triangles per 4 x f32x4)
+    float edge_max;          // triangles: largest |component| of any edge vector A, B of the group
+    float reach;             // triangles: largest |coordinate| of any corner or bounding-sphere centre
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -74,6 +76,8 @@ struct SceneRec {
     const TextureRec* textures;   // 16 slots
     const CameraRec* cam;
     const f32x4* pairs;           // sphere and triangle groups again, two primitives per record (group loops)
+    const f32x4* bounds;          // per triangle: bounding sphere and B x A, two triangles per record
+    int prefilter;                // 1: triangle loops reject by bounding sphere first
     float horizon[3], zenith[3];
     int n_groups;
 };
@@ -170,7 +174,7 @@ struct Closest {
 struct Ray { float ox, oy, oz, dx, dy, dz; };
 
 // What the reference would have evaluated, for the roofline accounting
-struct PairCounts { unsigned long long sphere, triangle, cull, disk, sphere_slots, triangle_slots; };
+struct PairCounts { unsigned long long sphere, triangle, cull, disk, sphere_slots, triangle_slots, triangle_exact; };
 
 // ---- one (ray, primitive) pair, exactly as the reference evaluates it ------
 // sphere_group.py:137-205.  `s` = (centre, radius^2).
@@ -303,11 +307,22 @@ __device__ __forceinline__ f32x2 sphere_discriminant2(const Ray2& r, const Spher
 // in a short queue in LDS, in index order, and the wavefront works the queues
 // off together afterwards, each lane fetching its own primitives: a few
 // trips per group instead of one per candidate.
-enum { QUEUE_SLOTS = 8 };
+enum { QUEUE_SLOTS = 12 };
 struct LaneQueue {
     unsigned* slot;     // slot[k * 64]: k-th queued primitive (index inside the group) of this lane
     int n;
+    long long drain_ticks;   // builds with WRT_TIMING: time spent working queues off
 };
+#ifndef WRT_TIMING
+#define WRT_TIMING 0
+#endif
+#if WRT_TIMING
+#define WRT_DRAIN_BEGIN(q) const long long drain_began = (long long)__builtin_readcyclecounter()
+#define WRT_DRAIN_END(q) ((q).drain_ticks += (long long)__builtin_readcyclecounter() - drain_began)
+#else
+#define WRT_DRAIN_BEGIN(q) ((void)0)
+#define WRT_DRAIN_END(q) ((void)0)
+#endif
 __device__ __forceinline__ void push(LaneQueue& q, bool take, int index) {
     if (take) { q.slot[q.n * 64] = (unsigned)index; ++q.n; }
 }
@@ -319,6 +334,7 @@ __device__ __forceinline__ bool short_of_room(const LaneQueue& q, int entries) {
 // sphere_group.py:190-213 for the queued spheres of each lane
 __device__ __forceinline__ void drain_spheres(const SceneRec& S, LaneQueue& q, int g, int first, const Ray& r,
                                               float t_min, float sentinel, Closest& best) {
+    WRT_DRAIN_BEGIN(q);
     for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
         if (k < q.n) {
             const int prim = first + (int)q.slot[k * 64];
@@ -330,6 +346,7 @@ __device__ __forceinline__ void drain_spheres(const SceneRec& S, LaneQueue& q, i
         }
     }
     q.n = 0;
+    WRT_DRAIN_END(q);
 }
 
 // one vote for two spheres; the lanes that have to look at one note it down
@@ -411,6 +428,7 @@ struct TriangleWalk { float t_min, t_max, t_lo, t_hi, t_cap; };
 // triangle_group.py:302-399 for the queued triangles of each lane
 __device__ __forceinline__ void drain_triangles(const SceneRec& S, LaneQueue& q, int g, int first, bool active,
                                                 const Ray& r, TriangleWalk& w, Closest& best) {
+    WRT_DRAIN_BEGIN(q);
     for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
         if (k < q.n) {
             const int prim = first + (int)q.slot[k * 64];
@@ -423,6 +441,7 @@ __device__ __forceinline__ void drain_triangles(const SceneRec& S, LaneQueue& q,
     q.n = 0;
     // inactive lanes keep an unreachable cap
     w.t_cap = active ? fminf(w.t_hi, best.t * 1.00001f) : -__builtin_inff();
+    WRT_DRAIN_END(q);
 }
 
 // one vote for two triangles; the lanes that have to look at one note it down
@@ -466,6 +485,139 @@ __device__ __forceinline__ void loop_triangles(const SceneRec& S, const WRT_CONS
         triangle_step(A, 2 * j, count, r2, w, q);
     }
     drain_triangles(S, q, g, first, active, r, w, best);
+}
+
+// ---- triangle loop with a bounding-sphere reject in front ---------------------
+// Möller-Trumbore on every pair costs the wavefront ~29 packed instructions
+// per triangle; a ray misses nearly all triangles of a mesh by a wide margin.
+// Each triangle therefore carries the smallest sphere around its three
+// corners, and the loop first asks whether the ray's line comes near that
+// sphere (~11 packed instructions per triangle, fused multiply-adds allowed
+// because the test only has to be safe, not identical).  Lanes queue the
+// triangles that survive, four per vote, and the exact evaluation above runs
+// on those alone.
+//
+// Safety: the test must keep every pair for which the reference's float32
+// arithmetic reports a hit, rounding errors included.  With u = 2^-24,
+// D = max|d_i|, T >= max|o_i - P0_i|, M = largest edge component, the
+// reference's determinant and its u, v numerators differ from their exact
+// values by at most E_det = 32u D M^2 and E = 40u D T M (three-term float32 dot
+// products of two-term cross products).  The reference reports a hit only if
+// |det| >= 1e-5 and u >= 0, v >= 0, u + v <= 1 as computed, so for
+// E_det <= 5e-6 the exact intersection point of the line with the triangle's
+// plane has barycentric coordinates u* >= -E/|det*|, v* >= -E/|det*|,
+// u* + v* <= 1 + (3E + E_det)/|det*| + 5u and lies within
+// rho = 208u D M^2 (T + M) / |det*| + 9e-7 M of the triangle (edge lengths
+// are at most sqrt(3) M).  The line thus passes within r + rho of the sphere's
+// centre.  |det*| is bounded from below with det' = d . (B x A) from the
+// precomputed normal (error at most 24u D M^2 <= |det'|/2 when |det'| >= 1e-5):
+// |det*| >= max(|det'|, 1e-5) / 2.  The squared-distance test itself is
+// evaluated in float32 with fused multiply-adds, error at most
+// 40u |d|^2 |o - c|^2, covered by `slack`.  A lane whose ray is too long or
+// whose group has edges too large for E_det <= 5e-6 makes its wavefront fall
+// back to the loop above.
+struct BoundPair { f32x2 cx, cy, cz, r, nx, ny, nz; };                // 4 x f32x4 (last two floats unused)
+enum { BOUND_PAIR_VECS = 4 };
+__device__ __forceinline__ BoundPair fetch_bound_pair(const WRT_CONST f32x4* p) {
+    const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
+    return BoundPair{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}, {v[12], v[13]}};
+}
+
+struct SphereReject {
+    float dd;        // |d|^2
+    float widen;     // 2 * 208u D M^2 (T + M), rounded up
+    float slack;     // float32 error allowance of the squared-distance test; -inf for lanes that ride along
+    bool usable;     // the bounds of the error analysis hold for this lane
+};
+__device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool active, float edge_max, float reach) {
+    SphereReject k;
+    const float D = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
+    const float O = fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz));
+    const float T = O + reach;
+    k.dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    k.widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
+    k.slack = active ? 3.9e-6f * k.dd * (3.0f * T * T) : -__builtin_inff();
+    // written so that a NaN or infinite ray is not usable
+    k.usable = !active || (D * edge_max * edge_max <= 2.5f && T <= 1.0e15f);
+    return k;
+}
+
+// sign bit set in a half of the result: the exact evaluation cannot report a hit
+__device__ __forceinline__ f32x2 sphere_reject2(const Ray2& r, const SphereReject& k, const BoundPair& b) {
+    const f32x2 cox = r.ox - b.cx, coy = r.oy - b.cy, coz = r.oz - b.cz;
+    const f32x2 h = __builtin_elementwise_fma(r.dz, coz, __builtin_elementwise_fma(r.dy, coy, r.dx * cox));
+    const f32x2 cc = __builtin_elementwise_fma(coz, coz, __builtin_elementwise_fma(coy, coy, cox * cox));
+    const f32x2 det = __builtin_elementwise_fma(r.dz, b.nz, __builtin_elementwise_fma(r.dy, b.ny, r.dx * b.nx));
+    const f32x2 inv = {__builtin_amdgcn_rcpf(fmaxf(fabsf(det.x), 0.00001f)),
+                       __builtin_amdgcn_rcpf(fmaxf(fabsf(det.y), 0.00001f))};
+    const f32x2 widen = {k.widen, k.widen}, dd = {k.dd, k.dd}, slack = {k.slack, k.slack};
+    const f32x2 q = __builtin_elementwise_fma(widen, inv, b.r);            // r + rho
+    const f32x2 t1 = __builtin_elementwise_fma(-q, q, cc);
+    const f32x2 t2 = __builtin_elementwise_fma(dd, t1, -slack);           // |d|^2 (|co|^2 - (r + rho)^2) - slack
+    return __builtin_elementwise_fma(h, h, -t2);                          // >= 0: the line comes near enough
+}
+
+// Queue entries of this loop: (index of the group of four triangles) * 16 + one bit
+// per triangle, set = rejected.
+__device__ __forceinline__ void drain_triangle_quads(const SceneRec& S, LaneQueue& q, int g, int first, const Ray& r,
+                                                     const TriangleWalk& w, Closest& best,
+                                                     unsigned long long& evaluated) {
+    WRT_DRAIN_BEGIN(q);
+    for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
+        const unsigned entry = (k < q.n) ? q.slot[k * 64] : 15u;
+        unsigned open = ~entry & 15u;
+        const int quad_first = first + 4 * (int)(entry >> 4);
+        while (true) {
+            const unsigned long long todo = __ballot(open != 0u);
+            if (todo == 0ull) break;
+            evaluated += (unsigned)__popcll(todo);
+            if (open != 0u) {
+                const int prim = quad_first + (int)__builtin_ctz(open);
+                open &= open - 1u;
+                const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
+                const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
+                float t;
+                if (triangle_exact(terms, w.t_min, w.t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
+            }
+        }
+    }
+    q.n = 0;
+    WRT_DRAIN_END(q);
+}
+
+// `records`: the group's bounding records, 4 x f32x4 per two triangles, whole fours
+__device__ __forceinline__ void loop_triangles_rejecting(const SceneRec& S, const WRT_CONST f32x4* records, int g,
+                                                         int first, int count, const SphereReject& k, const Ray& r,
+                                                         float t_min, float t_max, LaneQueue& q, Closest& best,
+                                                         unsigned long long& evaluated) {
+    const TriangleWalk w = {t_min, t_max, 0.0f, 0.0f, 0.0f};
+    const Ray2 r2 = both_halves(r);
+    const int quads = (count + 3) >> 2;
+    BoundPair A = fetch_bound_pair(records), B;
+    for (int j = 0; j < quads; ++j) {
+        WRT_SCALAR_LOADS_ARRIVED();
+        B = fetch_bound_pair(records + 4);
+        WRT_PIN();
+        const f32x2 da = sphere_reject2(r2, k, A);
+        WRT_SCALAR_LOADS_ARRIVED();
+        A = fetch_bound_pair(records + 8);
+        WRT_PIN();
+        const f32x2 db = sphere_reject2(r2, k, B);
+        records += 8;
+        // the four sign bits; triangles past the group's end count as rejected
+        const unsigned past = (4 * j + 4 > count) ? (15u << (count - 4 * j)) & 15u : 0u;
+        unsigned bits = __float_as_uint(da.x) >> 31;
+        bits |= (__float_as_uint(da.y) >> 31) << 1;
+        bits |= (__float_as_uint(db.x) >> 31) << 2;
+        bits |= (__float_as_uint(db.y) >> 31) << 3;
+        const unsigned entry = ((unsigned)j << 4) | past | bits;
+        // every lane writes its next slot; only lanes with an open bit keep it
+        q.slot[q.n * 64] = entry;
+        q.n += ((entry & 15u) != 15u) ? 1 : 0;
+        if (__ballot(q.n >= QUEUE_SLOTS) != 0ull) drain_triangle_quads(S, q, g, first, r, w, best, evaluated);
+    }
+    WRT_SCALAR_LOADS_ARRIVED();
+    drain_triangle_quads(S, q, g, first, r, w, best, evaluated);
 }
 
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
@@ -517,8 +669,13 @@ __device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int 
             if (pass_mask == 0ull) continue;
             pc.triangle += (unsigned long long)__popcll(pass_mask) * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
-            loop_triangles(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, pass, r, t_min, t_max, q,
-                           best);
+            const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach);
+            if (S.prefilter && __ballot(!k.usable) == 0ull)
+                loop_triangles_rejecting(S, as_uniform(S.bounds) + groups[g].bound_base, g, first, count, k, r, t_min,
+                                         t_max, q, best, pc.triangle_exact);
+            else
+                loop_triangles(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, pass, r, t_min, t_max, q,
+                               best);
         } else {
             pc.disk += n_live;
             float c[4], n[4];

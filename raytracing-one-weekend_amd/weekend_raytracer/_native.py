@@ -42,7 +42,7 @@ class WrtStats(ctypes.Structure):
         ("paths", ctypes.c_uint64), ("sphere_pairs", ctypes.c_uint64), ("triangle_pairs", ctypes.c_uint64),
         ("cull_tests", ctypes.c_uint64), ("disk_pairs", ctypes.c_uint64),
         ("sphere_lane_slots", ctypes.c_uint64), ("triangle_lane_slots", ctypes.c_uint64),
-        ("clock_ticks", ctypes.c_uint64 * 8),
+        ("clock_ticks", ctypes.c_uint64 * 8), ("triangle_evaluations", ctypes.c_uint64),
     ]
 
 
@@ -69,6 +69,7 @@ SIGNATURES = {
     "wrt_finalize": [_vp, _vp, _i64, _i, _vp, _vp],
     "wrt_profile_enable": [_vp, _i],
     "wrt_profile_read": [_vp, ctypes.POINTER(ctypes.c_double), _ip],
+    "wrt_set_triangle_reject": [_vp, _i],
     "wrt_stats_reset": [_vp, _vp],
     "wrt_stats_read": [_vp, ctypes.POINTER(WrtStats), _vp],
     "wrt_generate_rays": [_vp, _i, _i, _i, _i, _u64, _vp, _vp, _vp],
@@ -316,6 +317,10 @@ class Context:
         self.check(self.lib.wrt_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n)), "wrt_profile_read")
         return ms.value, n.value
 
+    def set_triangle_reject(self, on):
+        """Bounding-sphere test in front of the triangle evaluation (default on); same results either way."""
+        self.check(self.lib.wrt_set_triangle_reject(self.handle, 1 if on else 0), "wrt_set_triangle_reject")
+
     def stats_reset(self):
         self.check(self.lib.wrt_stats_reset(self.handle, self.stream()), "wrt_stats_reset")
 
@@ -326,7 +331,8 @@ class Context:
                     sphere_pairs=int(s.sphere_pairs), triangle_pairs=int(s.triangle_pairs),
                     cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs),
                     sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots),
-                    clock_ticks=np.array(list(s.clock_ticks), dtype=np.int64))
+                    clock_ticks=np.array(list(s.clock_ticks), dtype=np.int64),
+                    triangle_evaluations=int(s.triangle_evaluations))
 
 
 _contexts = {}

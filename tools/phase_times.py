@@ -33,7 +33,7 @@ def run(name):
     t = st["clock_ticks"].astype(float)
     waves = ctx.compute_units * 32
     names = ["sum of wave lifetimes", "longest lifetime", "triangle loops", "sphere loops", "shading", "refill",
-             "per-lane walk", "group loops run"]
+             "per-lane walk", "queues"]
     print(f"{name}: kernel {ms:.2f} ms in {launches} launch(es), {waves} waves")
     if t[0] == 0:
         print("  no clock tallies: library not built with -DWRT_TIMING=1")
@@ -47,7 +47,11 @@ def run(name):
         print(f"  triangle step (2 triangles x 64 lanes): {t[2] / steps[0]:.1f} ticks of one wave")
     if steps[1]:
         print(f"  sphere step (2 spheres x 64 lanes):     {t[3] / steps[1]:.1f} ticks of one wave")
-    print(f"  loops run {int(t[7])}, lane efficiency tri {st['triangle_pairs'] / max(1, st['triangle_lane_slots']):.3f} "
+    print(f"  working queues off     {100 * t[7] / t[0]:6.2f} % of wave time (inside the loops)")
+    if st["triangle_pairs"]:
+        print(f"  triangle pairs fully evaluated: {st['triangle_evaluations'] / st['triangle_pairs']:.4f} of all, "
+              f"{st['triangle_evaluations'] / max(1, st['cull_tests']):.2f} per (ray, group)")
+    print(f"  lane efficiency tri {st['triangle_pairs'] / max(1, st['triangle_lane_slots']):.3f} "
           f"sph {st['sphere_pairs'] / max(1, st['sphere_lane_slots']):.3f}")
     ctx.close()
 
