@@ -86,7 +86,23 @@ __device__ __forceinline__ unsigned long long wave_sum_small(bool take, int coun
     return total;
 }
 
-__global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const SceneRec S, const RenderArgs A) {
+struct RenderLaunch { SceneRec S; RenderArgs A; };
+
+// A fresh look at a kernel's arguments.  The compiler cannot carry anything read
+// through the returned pointer across this call, so the values are fetched (scalar
+// loads, cached) in the phase that uses them instead of living in registers, or in
+// spill slots, for the whole run of a persistent kernel.
+template <typename T>
+__device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
+    unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (const WRT_CONST T*)p;
+#pragma clang diagnostic pop
+}
+
+__global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     const unsigned lane = threadIdx.x & 63u;
     LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0};
@@ -94,21 +110,26 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     long long batch = 0;
     unsigned batch_used = 64;
     bool drained = false;              // the launch has no batch left
-    const int n_groups = S.n_groups;
-    const float sentinel = A.t_max + 1.0f;
-    const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
+    int n_groups;
+    float sentinel, t_min, t_max;
+    uint32_t k0, k1;
+    {
+        const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
+        n_groups = L.S.n_groups; t_min = L.A.t_min; t_max = L.A.t_max; k0 = L.A.k0; k1 = L.A.k1;
+        sentinel = t_max + 1.0f;
+    }
 
     int state = LANE_DEAD;
     int g = 0;                         // next group of the current segment
     Closest best = {sentinel, -1, -1};
     PathKey key;
-    key.k0 = A.k0; key.k1 = A.k1; key.x = key.y = key.s = 0;
+    key.k0 = k0; key.k1 = k1; key.x = key.y = key.s = 0;
     int bounce = 0;
     Ray ray = {0, 0, 0, 0, 0, 1};
     float cr = 1, cg = 1, cb = 1;
     PairCounts pc = {0, 0, 0, 0, 0, 0, 0};
     // slot of a path in the output, ray-id order r = (x*H + y)*S + s (main.py:102-104)
-    auto out_slot = [&](const PathKey& k) {
+    auto out_slot = [](const WRT_CONST RenderArgs& A, const PathKey& k) {
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
     };
 
@@ -118,8 +139,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         long long since = WRT_CLOCK();
         // ---- (a) segments that have seen every group: shade, scatter or end --
         if (state == LANE_ADVANCE && g == n_groups) {
+            const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
+            SceneArg S = L.S;
+            const WRT_CONST RenderArgs& A = L.A;
             bool done;
-            if (best.t < A.t_max) {
+            if (best.t < t_max) {
                 HitRecord h;
                 shade_record(S, best, ray, h);
                 const MaterialRec& M = S.materials[h.material];
@@ -149,7 +173,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             }
             if (done) {
                 f32x4 rec = {cr, cg, cb, (float)mark};
-                reinterpret_cast<f32x4*>(A.paths)[out_slot(key)] = rec;
+                reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
                 state = LANE_DEAD;
             } else {
                 g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
@@ -162,6 +186,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         for (int pass = 0; pass < 2; ++pass) {
             const unsigned long long dead = __ballot(state == LANE_DEAD);
             if (dead == 0ull || drained) break;
+            const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
+            SceneArg S = L.S;
+            const WRT_CONST RenderArgs& A = L.A;
             if (batch_used == 64) {
                 unsigned long long taken = 0;
                 if (lane == 0) taken = atomicAdd(A.next_batch, 1ull);
@@ -182,7 +209,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                     if (A.max_bounces == 0) {
                         // bounce 0 is already the limit: zeroed untraced (main.py:211-212)
                         f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
-                        reinterpret_cast<f32x4*>(A.paths)[out_slot(key)] = rec;
+                        reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
                     } else {
                         float o[3], d[3];
                         camera_ray(*S.cam, A.width, A.height, key, o, d);
@@ -201,6 +228,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         // ---- (c) walk the groups a lane can handle on its own ----------------
         // The loop is wave-uniform (it runs while any lane still advances) so that the
         // tallies can be kept in scalar registers.
+        SceneArg S = kernel_arguments<RenderLaunch>()->S;
         while (true) {
             const bool adv = (state == LANE_ADVANCE) && (g < n_groups);
             if (__ballot(adv) == 0ull) break;
@@ -216,7 +244,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                         state = LANE_PARKED; count = 0;
                     } else {
                         small = true;
-                        lane_triangles(S, g, first, count, ray, A.t_min, A.t_max, best);
+                        lane_triangles(S, g, first, count, ray, t_min, t_max, best);
                         ++g;
                     }
                 } else if (type == GROUP_SPHERES) {
@@ -224,12 +252,12 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                         state = LANE_PARKED; count = 0;
                     } else {
                         small = true;
-                        lane_spheres(S, g, first, count, ray, A.t_min, sentinel, best);
+                        lane_spheres(S, g, first, count, ray, t_min, sentinel, best);
                         ++g;
                     }
                 } else {
                     float t;
-                    if (disk_hit(ray, G.c, G.n, A.t_min, A.t_max, sentinel, t) && t < best.t) {
+                    if (disk_hit(ray, G.c, G.n, t_min, t_max, sentinel, t) && t < best.t) {
                         best.t = t; best.group = g; best.prim = 0;
                     }
                     ++g;
@@ -259,6 +287,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             if (n > run_n) { run_n = n; run_g = cand; }
             rest &= ~same;
         }
+        const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
         const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
         const WRT_CONST f32x4* records = as_uniform(S.pairs) + ugroups[run_g].pair_base;
         if (more_cheap) {
@@ -275,19 +304,20 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach);
             if (S.prefilter && __ballot(!k.usable) == 0ull)
                 loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count, k,
-                                         ray, A.t_min, A.t_max, queue, best, pc.triangle_exact);
+                                         ray, t_min, t_max, queue, best, pc.triangle_exact);
             else
-                loop_triangles(S, records, run_g, first, count, mine, ray, A.t_min, A.t_max, queue, best);
+                loop_triangles(S, records, run_g, first, count, mine, ray, t_min, t_max, queue, best);
             WRT_TALLY(2, since);
         } else {
             pc.sphere += (unsigned long long)run_n * (unsigned)count;
             pc.sphere_slots += 64ull * (unsigned)count;
-            loop_spheres(S, records, run_g, first, count, mine, ray, A.t_min, sentinel, queue, best);
+            loop_spheres(S, records, run_g, first, count, mine, ray, t_min, sentinel, queue, best);
             WRT_TALLY(3, since);
         }
         if (mine) { state = LANE_ADVANCE; ++g; }
     }
     // tallies: one atomic per counter per wave
+    const WRT_CONST RenderArgs& A = kernel_arguments<RenderLaunch>()->A;
     if (lane == 0) {
         if (pc.sphere) atomicAdd(&A.stats[STAT_PATHS + 1], pc.sphere);
         if (pc.triangle) atomicAdd(&A.stats[STAT_PATHS + 2], pc.triangle);
@@ -343,8 +373,9 @@ __global__ void k_finalize(const float* __restrict__ accum, long long n, float s
     if (i < n) image[i] = sqrtf(accum[i] / spp);
 }
 
-__global__ void k_generate_rays(const SceneRec S, int width, int height, int s_begin, int n_samples,
+__global__ void k_generate_rays(const SceneRec, int width, int height, int s_begin, int n_samples,
                                 uint32_t k0, uint32_t k1, float* __restrict__ origins, float* __restrict__ dirs) {
+    SceneArg S = *kernel_arguments<SceneRec>();   // the first argument, read in place
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long n = (long long)width * height * n_samples;
     if (i >= n) return;
@@ -364,9 +395,10 @@ struct IntersectOut {
     int32_t* hit_group; int32_t* prim;
 };
 
-__global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, const float* __restrict__ origins,
+__global__ __launch_bounds__(256) void k_intersect(const SceneRec, int group, const float* __restrict__ origins,
                                                    const float* __restrict__ dirs, long long n, float t_min,
                                                    float t_max, IntersectOut O) {
+    SceneArg S = *kernel_arguments<SceneRec>();   // the first argument, read in place
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     Ray ray = {0, 0, 0, 0, 0, 1};
@@ -405,13 +437,14 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec S, int group, 
     if (O.prim) O.prim[i] = prim;
 }
 
-__global__ __launch_bounds__(256) void k_scatter(const SceneRec S, int material_index, const float* __restrict__ dirs,
+__global__ __launch_bounds__(256) void k_scatter(const SceneRec, int material_index, const float* __restrict__ dirs,
                                                  const float* __restrict__ points, const float* __restrict__ normals,
                                                  const float* __restrict__ uvs, const uint8_t* __restrict__ back,
                                                  const int32_t* __restrict__ px, const int32_t* __restrict__ py,
                                                  const int32_t* __restrict__ ps, int bounce, uint32_t k0, uint32_t k1,
                                                  long long n, float* __restrict__ out_dirs,
                                                  float* __restrict__ out_colours, uint8_t* __restrict__ absorbed) {
+    SceneArg S = *kernel_arguments<SceneRec>();   // the first argument, read in place
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     HitRecord h;
@@ -910,7 +943,7 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
             HIP_TRY(ctx, hipEventCreate(&ev1));
             HIP_TRY(ctx, hipEventRecord(ev0, st));
         }
-        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, ctx->scene, A);
+        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, RenderLaunch{ctx->scene, A});
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->profiling) {
             HIP_TRY(ctx, hipEventRecord(ev1, st));

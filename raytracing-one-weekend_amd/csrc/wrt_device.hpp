@@ -82,6 +82,11 @@ struct SceneRec {
     int n_groups;
 };
 
+// The scene record is read where it lies, in the kernel-argument segment,
+// through scalar loads at the point of use: a persistent kernel that kept
+// its two dozen pointers in SGPRs from start to end would spill most of them.
+typedef const WRT_CONST SceneRec& SceneArg;
+
 // ------------------------------------------------------------------ RNG
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -332,7 +337,7 @@ __device__ __forceinline__ bool short_of_room(const LaneQueue& q, int entries) {
 }
 
 // sphere_group.py:190-213 for the queued spheres of each lane
-__device__ __forceinline__ void drain_spheres(const SceneRec& S, LaneQueue& q, int g, int first, const Ray& r,
+__device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
                                               float t_min, float sentinel, Closest& best) {
     WRT_DRAIN_BEGIN(q);
     for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
@@ -362,7 +367,7 @@ __device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int 
 }
 
 // `records`: the group's sphere pairs, 2 x f32x4 each
-__device__ __forceinline__ void loop_spheres(const SceneRec& S, const WRT_CONST f32x4* records, int g, int first,
+__device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
                                              int count, bool active, const Ray& r, float t_min, float sentinel,
                                              LaneQueue& q, Closest& best) {
     // inactive lanes can never pass the discriminant test
@@ -426,7 +431,7 @@ __device__ __forceinline__ f32x2 triangle_slack2(const TriTerms2& k, float t_lo,
 struct TriangleWalk { float t_min, t_max, t_lo, t_hi, t_cap; };
 
 // triangle_group.py:302-399 for the queued triangles of each lane
-__device__ __forceinline__ void drain_triangles(const SceneRec& S, LaneQueue& q, int g, int first, bool active,
+__device__ __forceinline__ void drain_triangles(SceneArg S, LaneQueue& q, int g, int first, bool active,
                                                 const Ray& r, TriangleWalk& w, Closest& best) {
     WRT_DRAIN_BEGIN(q);
     for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
@@ -457,7 +462,7 @@ __device__ __forceinline__ void triangle_step(const TriPair& rec, int index, int
 }
 
 // `records`: the group's triangle pairs, 5 x f32x4 each
-__device__ __forceinline__ void loop_triangles(const SceneRec& S, const WRT_CONST f32x4* records, int g, int first,
+__device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
                                                int count, bool active, const Ray& r, float t_min, float t_max,
                                                LaneQueue& q, Closest& best) {
     TriangleWalk w = {t_min, t_max, t_min * 0.99999f, t_max * 1.00001f, 0.0f};
@@ -559,26 +564,31 @@ __device__ __forceinline__ f32x2 sphere_reject2(const Ray2& r, const SphereRejec
 
 // Queue entries of this loop: (index of the group of four triangles) * 16 + one bit
 // per triangle, set = rejected.
-__device__ __forceinline__ void drain_triangle_quads(const SceneRec& S, LaneQueue& q, int g, int first, const Ray& r,
+__device__ __forceinline__ void drain_triangle_quads(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
                                                      const TriangleWalk& w, Closest& best,
                                                      unsigned long long& evaluated) {
     WRT_DRAIN_BEGIN(q);
-    for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
-        const unsigned entry = (k < q.n) ? q.slot[k * 64] : 15u;
-        unsigned open = ~entry & 15u;
-        const int quad_first = first + 4 * (int)(entry >> 4);
-        while (true) {
-            const unsigned long long todo = __ballot(open != 0u);
-            if (todo == 0ull) break;
-            evaluated += (unsigned)__popcll(todo);
-            if (open != 0u) {
-                const int prim = quad_first + (int)__builtin_ctz(open);
-                open &= open - 1u;
-                const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
-                const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
-                float t;
-                if (triangle_exact(terms, w.t_min, w.t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
-            }
+    // every lane walks its own entries and their open bits at its own pace, lowest index first:
+    // as many trips as the busiest lane has triangles to look at
+    int k = 0, quad_first = 0;
+    unsigned open = 0u;
+    while (true) {
+        if (open == 0u && k < q.n) {
+            const unsigned entry = q.slot[k * 64];
+            ++k;
+            open = ~entry & 15u;
+            quad_first = first + 4 * (int)(entry >> 4);
+        }
+        const unsigned long long todo = __ballot(open != 0u);
+        if (todo == 0ull) break;
+        evaluated += (unsigned)__popcll(todo);
+        if (open != 0u) {
+            const int prim = quad_first + (int)__builtin_ctz(open);
+            open &= open - 1u;
+            const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
+            const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
+            float t;
+            if (triangle_exact(terms, w.t_min, w.t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
         }
     }
     q.n = 0;
@@ -586,7 +596,7 @@ __device__ __forceinline__ void drain_triangle_quads(const SceneRec& S, LaneQueu
 }
 
 // `records`: the group's bounding records, 4 x f32x4 per two triangles, whole fours
-__device__ __forceinline__ void loop_triangles_rejecting(const SceneRec& S, const WRT_CONST f32x4* records, int g,
+__device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_CONST f32x4* records, int g,
                                                          int first, int count, const SphereReject& k, const Ray& r,
                                                          float t_min, float t_max, LaneQueue& q, Closest& best,
                                                          unsigned long long& evaluated) {
@@ -621,7 +631,7 @@ __device__ __forceinline__ void loop_triangles_rejecting(const SceneRec& S, cons
 }
 
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
-__device__ __forceinline__ void lane_spheres(const SceneRec& S, int g, int first, int count, const Ray& r,
+__device__ __forceinline__ void lane_spheres(SceneArg S, int g, int first, int count, const Ray& r,
                                              float t_min, float sentinel, Closest& best) {
     for (int j = 0; j < count; ++j) {
         const f32x4 s = S.sph[first + j];
@@ -634,7 +644,7 @@ __device__ __forceinline__ void lane_spheres(const SceneRec& S, int g, int first
     }
 }
 
-__device__ __forceinline__ void lane_triangles(const SceneRec& S, int g, int first, int count, const Ray& r,
+__device__ __forceinline__ void lane_triangles(SceneArg S, int g, int first, int count, const Ray& r,
                                                float t_min, float t_max, Closest& best) {
     for (int j = 0; j < count; ++j) {
         const f32x4 a = S.tri[2 * (first + j)], b = S.tri[2 * (first + j) + 1];
@@ -647,7 +657,7 @@ __device__ __forceinline__ void lane_triangles(const SceneRec& S, int g, int fir
 // One ray per lane against groups [g_begin, g_end), every lane walking the
 // groups together (stage entry point wrt_intersect).  Every lane of the
 // wavefront must call this; `live` masks lanes without a ray.
-__device__ __forceinline__ void closest_hit(const SceneRec& S, int g_begin, int g_end, bool live, const Ray& r,
+__device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, bool live, const Ray& r,
                                             float t_min, float t_max, LaneQueue& q, Closest& best, PairCounts& pc) {
     const float sentinel = t_max + 1.0f;
     best.t = sentinel; best.group = -1; best.prim = -1;
@@ -696,7 +706,7 @@ struct HitRecord {
 
 // Hit point, shading normal, uv, facing and material of the winning
 // primitive (sphere_group.py:225-259, triangle_group.py:414-450, disk.py:65-92).
-__device__ __forceinline__ void shade_record(const SceneRec& S, const Closest& best, const Ray& r, HitRecord& h) {
+__device__ __forceinline__ void shade_record(SceneArg S, const Closest& best, const Ray& r, HitRecord& h) {
     const float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
     const GroupRec& G = S.groups[best.group];
     const float t = best.t;
@@ -763,7 +773,7 @@ __device__ __forceinline__ bool odd_cell(double value) {
 
 // <Material>.scatter (materials.py) for one hit, float64 where main.render()'s
 // float64 hit arrays make the reference evaluate in float64.
-__device__ __forceinline__ void scatter_one(const SceneRec& S, const MaterialRec& M, const PathKey& key,
+__device__ __forceinline__ void scatter_one(SceneArg S, const MaterialRec& M, const PathKey& key,
                                             uint32_t bounce, float dx, float dy, float dz,
                                             const HitRecord& h, Scattered& out) {
     const double nx = h.n[0], ny = h.n[1], nz = h.n[2];
