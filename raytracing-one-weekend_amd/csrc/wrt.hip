@@ -825,9 +825,12 @@ int wrt_scene_commit(wrt_ctx* ctx) {
         for (int j = 0; j < g.count; j += 2) {
             const size_t a = (size_t)g.first + j, b = (size_t)g.first + (j + 1 < g.count ? j + 1 : j);
             if (g.type == GROUP_SPHERES) {
+                // radius^2 a little large: the loops compute an upper bound of the discriminant
                 const f32x4 sa = ctx->h_sph[a], sb = ctx->h_sph[b];
+                const float wa = std::nextafter((float)((double)sa.w * (1.0 + 4e-7)), INFINITY),
+                            wb = std::nextafter((float)((double)sb.w * (1.0 + 4e-7)), INFINITY);
                 ctx->h_pairs.push_back(f32x4{sa.x, sb.x, sa.y, sb.y});
-                ctx->h_pairs.push_back(f32x4{sa.z, sb.z, sa.w, sb.w});
+                ctx->h_pairs.push_back(f32x4{sa.z, sb.z, wa, wb});
             } else {
                 // (P0, A.x) (A.yz, B.xy) B.z -> P0x P0y | P0z Ax | Ay Az | Bx By | Bz
                 const f32x4 a0 = ctx->h_tri[2 * a], a1 = ctx->h_tri[2 * a + 1], b0 = ctx->h_tri[2 * b],

@@ -298,11 +298,19 @@ __device__ __forceinline__ Ray2 both_halves(const Ray& r) {
     return Ray2{{r.ox, r.ox}, {r.oy, r.oy}, {r.oz, r.oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}};
 }
 
-__device__ __forceinline__ f32x2 sphere_discriminant2(const Ray2& r, const SpherePair& s, f32x2& h) {
+// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres
+// in 12 packed instructions; it only has to be safe, so the dot products are fused.  With
+// u = 2^-24, co = o - c as rounded by both evaluations and cc = |co|^2, the reference's
+// float32 value is within (8.1 |d|^2 + 5) u cc + 2u r^2 of the exact h^2 - (cc - r^2), the
+// fused one within (7.1 |d|^2 + 5) u cc + 2u r'^2 of h^2 + r'^2 - cc.  The pair records carry
+// r'^2 = r^2 (1 + 4e-7) and `widen` = 17u (|d|^2 + 1), which covers the difference.
+__device__ __forceinline__ f32x2 sphere_discriminant_bound2(const Ray2& r, const SpherePair& s, float widen) {
     const f32x2 cox = r.ox - s.cx, coy = r.oy - s.cy, coz = r.oz - s.cz;
-    h = (r.dx * cox + r.dy * coy) + r.dz * coz;
-    const f32x2 c = ((cox * cox + coy * coy) + coz * coz) - s.r2;
-    return h * h - c;
+    const f32x2 h = __builtin_elementwise_fma(r.dz, coz, __builtin_elementwise_fma(r.dy, coy, r.dx * cox));
+    const f32x2 cc = __builtin_elementwise_fma(coz, coz, __builtin_elementwise_fma(coy, coy, cox * cox));
+    const f32x2 disc = __builtin_elementwise_fma(h, h, s.r2 - cc);
+    const f32x2 w = {widen, widen};
+    return __builtin_elementwise_fma(w, cc, disc);
 }
 
 // Candidates of the vote are not evaluated on the spot: a hit is rare for one
@@ -356,10 +364,9 @@ __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, i
 
 // one vote for two spheres; the lanes that have to look at one note it down
 // (index + 1 == count: the second half repeats the group's last sphere and is left out)
-__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int count, float thr, const Ray2& r2,
-                                            LaneQueue& q) {
-    f32x2 h;
-    const f32x2 d = sphere_discriminant2(r2, s, h);
+__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int count, float thr, float widen,
+                                            const Ray2& r2, LaneQueue& q) {
+    const f32x2 d = sphere_discriminant_bound2(r2, s, widen);
     if (__ballot(fmaxf(d.x, d.y) > thr) != 0ull) {
         push(q, d.x > thr, index);
         push(q, d.y > thr && index + 1 < count, index + 1);
@@ -370,8 +377,10 @@ __device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int 
 __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
                                              int count, bool active, const Ray& r, float t_min, float sentinel,
                                              LaneQueue& q, Closest& best) {
-    // inactive lanes can never pass the discriminant test
-    const float thr = active ? 0.00001f : __builtin_inff();
+    // inactive lanes can never pass the discriminant test; the threshold leaves room for the
+    // rounding of the bound's last operation
+    const float thr = active ? 0.00000999999f : __builtin_inff();
+    const float widen = 1.02e-6f * (((r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz) + 1.0f);
     const Ray2 r2 = both_halves(r);
     const int pairs = (count + 1) >> 1;
     SphereQuad A = fetch_sphere_quad(records), B;
@@ -381,23 +390,23 @@ __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* 
         if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
         WRT_PIN();
-        sphere_step(A.a, 2 * j, count, thr, r2, q);
-        sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
+        sphere_step(A.a, 2 * j, count, thr, widen, r2, q);
+        sphere_step(A.b, 2 * j + 2, count, thr, widen, r2, q);
         WRT_SCALAR_LOADS_ARRIVED();
         if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         A = fetch_sphere_quad(records + 8);
         WRT_PIN();
-        sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
-        sphere_step(B.b, 2 * j + 6, count, thr, r2, q);
+        sphere_step(B.a, 2 * j + 4, count, thr, widen, r2, q);
+        sphere_step(B.b, 2 * j + 6, count, thr, widen, r2, q);
         records += 8;
     }
     WRT_SCALAR_LOADS_ARRIVED();
     if (j < pairs) {                       // up to three pairs left: A holds two of them
         if (short_of_room(q, 6)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
-        sphere_step(A.a, 2 * j, count, thr, r2, q);
-        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
-        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
+        sphere_step(A.a, 2 * j, count, thr, widen, r2, q);
+        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, count, thr, widen, r2, q);
+        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, count, thr, widen, r2, q);
     }
     drain_spheres(S, q, g, first, r, t_min, sentinel, best);
 }
