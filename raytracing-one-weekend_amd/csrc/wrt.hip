@@ -737,7 +737,7 @@ int wrt_set_sky(wrt_ctx* ctx, const float horizon[3], const float zenith[3]) {
 }
 
 // Smallest sphere around the corners of each triangle of the large groups and B x A, two
-// triangles per record, padded to whole fours with the group's last triangle; the group's
+// triangles per record, padded to whole blocks of 16 with the group's last triangle; the group's
 // largest edge component and largest coordinate for the error bounds of the reject test.
 static void build_bounds(wrt_ctx* ctx) {
     ctx->h_bounds.clear();
@@ -745,7 +745,7 @@ static void build_bounds(wrt_ctx* ctx) {
         g.bound_base = (int)ctx->h_bounds.size();
         g.edge_max = 0.0f; g.reach = 0.0f;
         if (g.type != GROUP_TRIANGLES) continue;
-        const int padded = (g.count + 3) & ~3;
+        const int padded = (g.count + 15) & ~15;
         std::vector<float> cx(padded), cy(padded), cz(padded), rr(padded), nx(padded), ny(padded), nz(padded);
         double edge_max = 0.0, reach = 0.0;
         for (int j = 0; j < g.count; ++j) {
@@ -822,8 +822,11 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     for (GroupRec& g : ctx->h_groups) {
         g.pair_base = (int)ctx->h_pairs.size();
         if (g.type == GROUP_DISK) continue;
-        for (int j = 0; j < g.count; j += 2) {
-            const size_t a = (size_t)g.first + j, b = (size_t)g.first + (j + 1 < g.count ? j + 1 : j);
+        // whole pairs; the filler repeats the last primitive
+        const int padded = (g.count + 1) & ~1;
+        for (int j = 0; j < padded; j += 2) {
+            const size_t a = (size_t)g.first + (j < g.count ? j : g.count - 1),
+                         b = (size_t)g.first + (j + 1 < g.count ? j + 1 : g.count - 1);
             if (g.type == GROUP_SPHERES) {
                 // radius^2 a little large: the loops compute an upper bound of the discriminant
                 const f32x4 sa = ctx->h_sph[a], sb = ctx->h_sph[b];

@@ -322,7 +322,7 @@ __device__ __forceinline__ f32x2 sphere_discriminant_bound2(const Ray2& r, const
 // trips per group instead of one per candidate.
 enum { QUEUE_SLOTS = 12 };
 struct LaneQueue {
-    unsigned* slot;     // slot[k * 64]: k-th queued primitive (index inside the group) of this lane
+    unsigned* slot;     // slot[k * 64]: k-th entry of this lane (a primitive's index inside the group, or a block)
     int n;
     long long drain_ticks;   // builds with WRT_TIMING: time spent working queues off
 };
@@ -342,6 +342,34 @@ __device__ __forceinline__ void push(LaneQueue& q, bool take, int index) {
 // true when some lane's queue cannot take `entries` more: time to work the queues off
 __device__ __forceinline__ bool short_of_room(const LaneQueue& q, int entries) {
     return __ballot(q.n > QUEUE_SLOTS - entries) != 0ull;
+}
+
+// Block entries: the triangle reject loop looks at 16 triangles between two visits to the queue.
+// Each test leaves its verdict in a sign bit, v_alignbit shifts the sign bits of a block
+// into one mask (first primitive in bit 15), and a lane with any bit set appends
+// (block << 16 | mask).  Every lane writes its next slot each time; only a lane with a
+// bit set moves on to the slot after it.
+__device__ __forceinline__ unsigned shift_in_signs(unsigned mask, f32x2 v) {
+    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(v.x), 31);
+    return __builtin_amdgcn_alignbit(mask, __float_as_uint(v.y), 31);
+}
+__device__ __forceinline__ void note_block(LaneQueue& q, int block, unsigned mask) {
+    q.slot[q.n * 64] = ((unsigned)block << 16) | mask;
+    q.n += (mask != 0u) ? 1 : 0;
+}
+__device__ __forceinline__ bool queue_full(const LaneQueue& q) { return __ballot(q.n >= QUEUE_SLOTS) != 0ull; }
+// the lane's next primitive in index order, -1 when its entries are used up
+__device__ __forceinline__ int next_in_blocks(const LaneQueue& q, int& k, unsigned& open, int& block_first) {
+    if (open == 0u && k < q.n) {
+        const unsigned entry = q.slot[k * 64];
+        ++k;
+        open = entry & 0xffffu;
+        block_first = 16 * (int)(entry >> 16);
+    }
+    if (open == 0u) return -1;
+    const int bit = 31 - (int)__builtin_clz(open);
+    open &= ~(1u << bit);
+    return block_first + 15 - bit;
 }
 
 // sphere_group.py:190-213 for the queued spheres of each lane
@@ -508,8 +536,7 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 // corners, and the loop first asks whether the ray's line comes near that
 // sphere (~11 packed instructions per triangle, fused multiply-adds allowed
 // because the test only has to be safe, not identical).  Lanes queue the
-// triangles that survive, four per vote, and the exact evaluation above runs
-// on those alone.
+// triangles that survive and the exact evaluation above runs on those alone.
 //
 // Safety: the test must keep every pair for which the reference's float32
 // arithmetic reports a hit, rounding errors included.  With u = 2^-24,
@@ -542,21 +569,23 @@ struct SphereReject {
     float widen;     // 2 * 208u D M^2 (T + M), rounded up
     float slack;     // float32 error allowance of the squared-distance test; -inf for lanes that ride along
     bool usable;     // the bounds of the error analysis hold for this lane
+    bool active;     // the lane's ray is at this group
 };
 __device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool active, float edge_max, float reach) {
     SphereReject k;
+    k.active = active;
     const float D = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
     const float O = fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz));
     const float T = O + reach;
     k.dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
     k.widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
-    k.slack = active ? 3.9e-6f * k.dd * (3.0f * T * T) : -__builtin_inff();
+    k.slack = active ? 3.9e-6f * k.dd * (3.0f * T * T) + 1.0e-30f : -__builtin_inff();
     // written so that a NaN or infinite ray is not usable
     k.usable = !active || (D * edge_max * edge_max <= 2.5f && T <= 1.0e15f);
     return k;
 }
 
-// sign bit set in a half of the result: the exact evaluation cannot report a hit
+// sign bit set in a half of the result: the exact evaluation may report a hit
 __device__ __forceinline__ f32x2 sphere_reject2(const Ray2& r, const SphereReject& k, const BoundPair& b) {
     const f32x2 cox = r.ox - b.cx, coy = r.oy - b.cy, coz = r.oz - b.cz;
     const f32x2 h = __builtin_elementwise_fma(r.dz, coz, __builtin_elementwise_fma(r.dy, coy, r.dx * cox));
@@ -568,32 +597,25 @@ __device__ __forceinline__ f32x2 sphere_reject2(const Ray2& r, const SphereRejec
     const f32x2 q = __builtin_elementwise_fma(widen, inv, b.r);            // r + rho
     const f32x2 t1 = __builtin_elementwise_fma(-q, q, cc);
     const f32x2 t2 = __builtin_elementwise_fma(dd, t1, -slack);           // |d|^2 (|co|^2 - (r + rho)^2) - slack
-    return __builtin_elementwise_fma(h, h, -t2);                          // >= 0: the line comes near enough
+    return __builtin_elementwise_fma(-h, h, t2);                          // < 0: the line comes near enough
 }
 
-// Queue entries of this loop: (index of the group of four triangles) * 16 + one bit
-// per triangle, set = rejected.
-__device__ __forceinline__ void drain_triangle_quads(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
-                                                     const TriangleWalk& w, Closest& best,
-                                                     unsigned long long& evaluated) {
+// triangle_group.py:302-399 for the triangles each lane noted, lowest index first
+__device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
+                                                      const TriangleWalk& w, Closest& best,
+                                                      unsigned long long& evaluated) {
     WRT_DRAIN_BEGIN(q);
-    // every lane walks its own entries and their open bits at its own pace, lowest index first:
-    // as many trips as the busiest lane has triangles to look at
-    int k = 0, quad_first = 0;
+    // every lane walks its own entries at its own pace: as many trips as the busiest lane
+    // has triangles to look at
+    int k = 0, block_first = 0;
     unsigned open = 0u;
     while (true) {
-        if (open == 0u && k < q.n) {
-            const unsigned entry = q.slot[k * 64];
-            ++k;
-            open = ~entry & 15u;
-            quad_first = first + 4 * (int)(entry >> 4);
-        }
-        const unsigned long long todo = __ballot(open != 0u);
+        const int index = next_in_blocks(q, k, open, block_first);
+        const unsigned long long todo = __ballot(index >= 0);
         if (todo == 0ull) break;
         evaluated += (unsigned)__popcll(todo);
-        if (open != 0u) {
-            const int prim = quad_first + (int)__builtin_ctz(open);
-            open &= open - 1u;
+        if (index >= 0) {
+            const int prim = first + index;
             const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
             const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
             float t;
@@ -604,39 +626,37 @@ __device__ __forceinline__ void drain_triangle_quads(SceneArg S, LaneQueue& q, i
     WRT_DRAIN_END(q);
 }
 
-// `records`: the group's bounding records, 4 x f32x4 per two triangles, whole fours
+// `records`: the group's bounding records, 4 x f32x4 per two triangles, whole blocks of 16 triangles
 __device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_CONST f32x4* records, int g,
                                                          int first, int count, const SphereReject& k, const Ray& r,
                                                          float t_min, float t_max, LaneQueue& q, Closest& best,
                                                          unsigned long long& evaluated) {
     const TriangleWalk w = {t_min, t_max, 0.0f, 0.0f, 0.0f};
     const Ray2 r2 = both_halves(r);
-    const int quads = (count + 3) >> 2;
+    const int blocks = (count + 15) >> 4;
     BoundPair A = fetch_bound_pair(records), B;
-    for (int j = 0; j < quads; ++j) {
-        WRT_SCALAR_LOADS_ARRIVED();
-        B = fetch_bound_pair(records + 4);
-        WRT_PIN();
-        const f32x2 da = sphere_reject2(r2, k, A);
-        WRT_SCALAR_LOADS_ARRIVED();
-        A = fetch_bound_pair(records + 8);
-        WRT_PIN();
-        const f32x2 db = sphere_reject2(r2, k, B);
-        records += 8;
-        // the four sign bits; triangles past the group's end count as rejected
-        const unsigned past = (4 * j + 4 > count) ? (15u << (count - 4 * j)) & 15u : 0u;
-        unsigned bits = __float_as_uint(da.x) >> 31;
-        bits |= (__float_as_uint(da.y) >> 31) << 1;
-        bits |= (__float_as_uint(db.x) >> 31) << 2;
-        bits |= (__float_as_uint(db.y) >> 31) << 3;
-        const unsigned entry = ((unsigned)j << 4) | past | bits;
-        // every lane writes its next slot; only lanes with an open bit keep it
-        q.slot[q.n * 64] = entry;
-        q.n += ((entry & 15u) != 15u) ? 1 : 0;
-        if (__ballot(q.n >= QUEUE_SLOTS) != 0ull) drain_triangle_quads(S, q, g, first, r, w, best, evaluated);
+    for (int block = 0; block < blocks; ++block) {
+        unsigned mask = 0u;
+#pragma unroll
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            WRT_SCALAR_LOADS_ARRIVED();
+            B = fetch_bound_pair(records + 4);
+            WRT_PIN();
+            mask = shift_in_signs(mask, sphere_reject2(r2, k, A));
+            WRT_SCALAR_LOADS_ARRIVED();
+            A = fetch_bound_pair(records + 8);
+            WRT_PIN();
+            mask = shift_in_signs(mask, sphere_reject2(r2, k, B));
+            records += 8;
+        }
+        // triangles past the group's end repeat its last one and are left out
+        const int left = count - 16 * block;
+        if (left < 16) mask &= 0xffffu << (16 - left);
+        note_block(q, block, k.active ? mask : 0u);         // (a NaN ray's verdicts are arbitrary)
+        if (queue_full(q)) drain_triangle_blocks(S, q, g, first, r, w, best, evaluated);
     }
     WRT_SCALAR_LOADS_ARRIVED();
-    drain_triangle_quads(S, q, g, first, r, w, best, evaluated);
+    drain_triangle_blocks(S, q, g, first, r, w, best, evaluated);
 }
 
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
