@@ -110,3 +110,21 @@ def test_reject_on_scaled_meshes_matches_oracle(scale, offset, falls_back):
     want = numpy_path.render(scene, w, h, s, b, seed=11)
     same = np.all(p_on[:, :3] == want["path_colours"], axis=1)
     assert same.mean() >= 0.995, same.mean()
+
+
+def test_reruns_are_bit_identical():
+    """Which wavefront traces a batch depends on timing (batches come from one counter); every
+    path's record must not."""
+    import torch
+    from weekend_raytracer import main, scenes
+    w, h, s, b = 640, 360, 8, 10
+    objs = scene_objects(scenes.cloth_bunny_scene, w / h)
+    frame = main.Frame(objs)
+    runs = []
+    for _ in range(3):
+        paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
+        accum = frame.accumulate(w, h, 0, s, b, 99, paths=paths)
+        runs.append((paths.cpu().numpy().view(np.uint32), accum.cpu().numpy().view(np.uint32)))
+    frame.ctx.close()
+    for p, a in runs[1:]:
+        assert np.array_equal(p, runs[0][0]) and np.array_equal(a, runs[0][1])
