@@ -62,15 +62,24 @@ enum { LANE_DEAD = 0, LANE_ADVANCE = 1, LANE_PARKED = 2 };
 #endif
 
 static constexpr int CHEAP_GROUP_MAX = 8;      // groups up to this size are evaluated per lane
-static constexpr int TRIP_COST = 1500;         // wave-instructions of one shade/refill/advance trip (estimate)
-static constexpr int TRIANGLE_COST = 60;       // wave-instructions per primitive of the uniform loops (estimate)
-static constexpr int SPHERE_COST = 25;
+#ifndef WRT_TRIP_COST
+#define WRT_TRIP_COST 1500
+#endif
+#ifndef WRT_TRIANGLE_COST
+#define WRT_TRIANGLE_COST 16
+#endif
+#ifndef WRT_SPHERE_COST
+#define WRT_SPHERE_COST 9
+#endif
+static constexpr int TRIP_COST = WRT_TRIP_COST;          // wave-instructions of one shade/refill/advance trip (estimate)
+static constexpr int TRIANGLE_COST = WRT_TRIANGLE_COST;  // wave-instructions per primitive of the uniform loops (estimate)
+static constexpr int SPHERE_COST = WRT_SPHERE_COST;
 
-// 8 waves per SIMD (64 VGPRs): the shading code spills to scratch, the group
-// loops do not, and the extra waves hide the scalar-load and branch latencies
-// of the loops (+11 % over 4 waves per SIMD on the bunny workload)
+// Waves per SIMD the kernel is compiled for: 6 (80 VGPRs) measures 1-1.5 % faster than 8
+// (64 VGPRs, more of the shading code in scratch) and 4-7 % faster than 4; the extra
+// waves hide the scalar-load, branch and gather latencies of the loops and queues.
 #ifndef WRT_WAVES_PER_SIMD
-#define WRT_WAVES_PER_SIMD 8
+#define WRT_WAVES_PER_SIMD 6
 #endif
 // Sum of `count` over the lanes with `take` set (each evaluated `count` pairs of
 // a small group on its own); must be called by the whole wave; wave-uniform result.
