@@ -113,8 +113,11 @@ __device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
 
 __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
+    // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
+    __shared__ float batch_rays[RENDER_BLOCK / 64][6][64];
     const unsigned lane = threadIdx.x & 63u;
     LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0};
+    float (*my_batch_rays)[64] = batch_rays[threadIdx.x >> 6];
     // the batch this wave is handing out to its lanes and how many of its 64 paths are gone
     long long batch = 0;
     unsigned batch_used = 64;
@@ -206,6 +209,20 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 batch = (long long)(((unsigned long long)hi << 32) | lo);
                 if (batch >= A.n_batches) { drained = true; break; }
                 batch_used = 0;
+                if (A.max_bounces != 0) {
+                    // every lane makes one ray of the batch, whatever path it carries itself
+                    const long long tile = batch / A.n_samples;
+                    PathKey fresh = key;
+                    fresh.x = (uint32_t)((int)(tile % A.tiles_x) * 8 + (int)(lane & 7u));
+                    fresh.y = (uint32_t)((int)(tile / A.tiles_x) * 8 + (int)(lane >> 3));
+                    fresh.s = (uint32_t)(A.s_begin + (int)(batch - tile * A.n_samples));
+                    if ((int)fresh.x < A.width && (int)fresh.y < A.height) {
+                        float o[3], d[3];
+                        camera_ray(*S.cam, A.width, A.height, fresh, o, d);
+                        my_batch_rays[0][lane] = o[0]; my_batch_rays[1][lane] = o[1]; my_batch_rays[2][lane] = o[2];
+                        my_batch_rays[3][lane] = d[0]; my_batch_rays[4][lane] = d[1]; my_batch_rays[5][lane] = d[2];
+                    }
+                }
             }
             const unsigned in_tile = batch_used + (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
             if (state == LANE_DEAD && in_tile < 64u) {
@@ -220,9 +237,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                         f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
                         reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
                     } else {
-                        float o[3], d[3];
-                        camera_ray(*S.cam, A.width, A.height, key, o, d);
-                        ray.ox = o[0]; ray.oy = o[1]; ray.oz = o[2]; ray.dx = d[0]; ray.dy = d[1]; ray.dz = d[2];
+                        ray.ox = my_batch_rays[0][in_tile]; ray.oy = my_batch_rays[1][in_tile];
+                        ray.oz = my_batch_rays[2][in_tile]; ray.dx = my_batch_rays[3][in_tile];
+                        ray.dy = my_batch_rays[4][in_tile]; ray.dz = my_batch_rays[5][in_tile];
                         cr = cg = cb = 1.0f;
                         bounce = 0;
                         g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
