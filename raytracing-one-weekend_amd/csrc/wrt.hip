@@ -115,8 +115,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
     __shared__ float batch_rays[RENDER_BLOCK / 64][6][64];
+    __shared__ unsigned share_list[RENDER_BLOCK / 64][SHARE_ITEMS];
+    __shared__ unsigned long long share_best[RENDER_BLOCK / 64][64];
     const unsigned lane = threadIdx.x & 63u;
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0};
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0, share_list[threadIdx.x >> 6],
+                       share_best[threadIdx.x >> 6], 0};
     float (*my_batch_rays)[64] = batch_rays[threadIdx.x >> 6];
     // the batch this wave is handing out to its lanes and how many of its 64 paths are gone
     long long batch = 0;
@@ -436,7 +439,10 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec, int group, co
     PairCounts pc = {0, 0, 0, 0, 0, 0, 0};
     const int g0 = group < 0 ? 0 : group, g1 = group < 0 ? S.n_groups : group + 1;
     __shared__ unsigned queue_slots[256 / 64][QUEUE_SLOTS][64];
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0, 0};
+    __shared__ unsigned share_list[256 / 64][SHARE_ITEMS];
+    __shared__ unsigned long long share_best[256 / 64][64];
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0, 0, share_list[threadIdx.x >> 6],
+                       share_best[threadIdx.x >> 6], 0};
     closest_hit(S, g0, g1, live, ray, t_min, t_max, queue, best, pc);
     if (!live) return;
     const bool hit = best.t < t_max;

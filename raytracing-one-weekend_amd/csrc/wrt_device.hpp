@@ -325,7 +325,11 @@ struct LaneQueue {
     unsigned* slot;     // slot[k * 64]: k-th entry of this lane (a primitive's index inside the group, or a block)
     int n;
     long long drain_ticks;   // builds with WRT_TIMING: time spent working queues off
+    unsigned* share_list;            // the wave's SHARE_ITEMS (owner lane << 24 | triangle) work items
+    unsigned long long* share_best;  // the wave's 64 (ordered t << 32 | triangle) minima, one per owner lane
+    int noted;                       // primitives in this lane's block entries
 };
+enum { SHARE_ITEMS = 384 };
 #ifndef WRT_TIMING
 #define WRT_TIMING 0
 #endif
@@ -356,6 +360,7 @@ __device__ __forceinline__ unsigned shift_in_signs(unsigned mask, f32x2 v) {
 __device__ __forceinline__ void note_block(LaneQueue& q, int block, unsigned mask) {
     q.slot[q.n * 64] = ((unsigned)block << 16) | mask;
     q.n += (mask != 0u) ? 1 : 0;
+    q.noted += __popc(mask);
 }
 __device__ __forceinline__ bool queue_full(const LaneQueue& q) { return __ballot(q.n >= QUEUE_SLOTS) != 0ull; }
 // the lane's next primitive in index order, -1 when its entries are used up
@@ -601,28 +606,85 @@ __device__ __forceinline__ f32x2 sphere_reject2(const Ray2& r, const SphereRejec
 }
 
 // triangle_group.py:302-399 for the triangles each lane noted, lowest index first
+// float -> unsigned with the same order (and back)
+__device__ __forceinline__ unsigned ordered_bits(float t) {
+    const unsigned b = __float_as_uint(t);
+    return b ^ ((b >> 31) != 0u ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned o) {
+    return __uint_as_float(o ^ ((o >> 31) != 0u ? 0x80000000u : 0xffffffffu));
+}
+
+// The lanes' lists differ a lot in length (a ray skimming the mesh passes through dozens of
+// bounding spheres, most pass through a few), so the wave pools them: every lane writes its
+// triangles into one list, the lanes then take 64 items at a time, each borrowing the owner's
+// ray (ds_bpermute), evaluating the pair exactly as above and lowering the owner's entry of
+// `share_best` with one 64-bit minimum: smaller t wins, equal t goes to the smaller index
+// (numpy.argmin, triangle_group.py:399), and an entry starts at (best.t, 0) so that an equal
+// t of this group never replaces a hit of an earlier group or drain (strict <, main.py:144).
 __device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
                                                       const TriangleWalk& w, Closest& best,
                                                       unsigned long long& evaluated) {
     WRT_DRAIN_BEGIN(q);
-    // every lane walks its own entries at its own pace: as many trips as the busiest lane
-    // has triangles to look at
-    int k = 0, block_first = 0;
-    unsigned open = 0u;
-    while (true) {
-        const int index = next_in_blocks(q, k, open, block_first);
-        const unsigned long long todo = __ballot(index >= 0);
-        if (todo == 0ull) break;
-        evaluated += (unsigned)__popcll(todo);
-        if (index >= 0) {
-            const int prim = first + index;
-            const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
-            const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
-            float t;
-            if (triangle_exact(terms, w.t_min, w.t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
+    const unsigned lane = threadIdx.x & 63u;
+    // where this lane's triangles go in the pooled numbering
+    const int mine = q.noted;
+    int upto = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int below = __shfl_up(upto, d, 64);
+        if ((int)lane >= d) upto += below;
+    }
+    const int before = upto - mine;
+    const int total = __builtin_amdgcn_readlane(upto, 63);
+    evaluated += (unsigned)total;
+    const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32);
+    q.share_best[lane] = start;
+    for (int chunk = 0; chunk < total; chunk += SHARE_ITEMS) {
+        // owners write their items of this chunk, entry by entry, lowest index first
+        int number = before - chunk;
+        for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
+            const unsigned entry = (k < q.n) ? q.slot[k * 64] : 0u;
+            unsigned open = entry & 0xffffu;
+            const unsigned tagged_first = (lane << 24) | (16u * (entry >> 16) + 15u);
+            while (__ballot(open != 0u) != 0ull) {
+                if (open != 0u) {
+                    const unsigned bit = 31u - (unsigned)__builtin_clz(open);
+                    open &= ~(1u << bit);
+                    if ((unsigned)number < (unsigned)SHARE_ITEMS) q.share_list[number] = tagged_first - bit;
+                    ++number;
+                }
+            }
+        }
+        const int items = total - chunk < SHARE_ITEMS ? total - chunk : SHARE_ITEMS;
+        for (int base = 0; base < items; base += 64) {
+            const bool have = base + (int)lane < items;
+            const unsigned item = have ? q.share_list[base + (int)lane] : 0u;
+            const int owner4 = (int)(item >> 24) * 4;
+            Ray borrowed;
+            borrowed.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
+            borrowed.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oy)));
+            borrowed.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oz)));
+            borrowed.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dx)));
+            borrowed.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dy)));
+            borrowed.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dz)));
+            if (have) {
+                const int prim = first + (int)(item & 0xffffffu);
+                const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
+                const TriTerms terms = triangle_terms(borrowed, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
+                float t;
+                if (triangle_exact(terms, w.t_min, w.t_max, t))
+                    atomicMin(&q.share_best[item >> 24],
+                              ((unsigned long long)ordered_bits(t) << 32) | (unsigned long long)(unsigned)prim);
+            }
         }
     }
+    const unsigned long long won = q.share_best[lane];
+    if (won != start) {
+        best.t = from_ordered_bits((unsigned)(won >> 32)); best.group = g; best.prim = (int)(unsigned)won;
+    }
     q.n = 0;
+    q.noted = 0;
     WRT_DRAIN_END(q);
 }
 

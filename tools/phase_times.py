@@ -31,7 +31,8 @@ def run(name):
     ms, launches = ctx.profile_read()
     st = ctx.stats()
     t = st["clock_ticks"].astype(float)
-    waves = ctx.compute_units * 32
+    # resident waves: a whole number per SIMD, a little above (sum of lifetimes / longest lifetime)
+    waves = max(1, round(t[0] / t[1] / 0.97 / (ctx.compute_units * 4))) * ctx.compute_units * 4 if st["clock_ticks"][1] else 0
     names = ["sum of wave lifetimes", "longest lifetime", "triangle loops", "sphere loops", "shading", "refill",
              "per-lane walk", "queues"]
     print(f"{name}: kernel {ms:.2f} ms in {launches} launch(es), {waves} waves")
