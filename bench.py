@@ -42,9 +42,9 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X spec (packed-FP32 issue), 256 CUs 
 
 WORKLOADS = {
     # name: (scene builder, width, height, spp, max_bounces, cpu sample (w, h, spp), description)
-    "cover": ("cover480", 1280, 720, 100, 10, (320, 180, 4),
+    "cover": ("cover480", 1280, 720, 100, 10, (320, 180, 8),
               "Book-1 cover scene, 484 spheres (480 random + 3 large + ground), depth-of-field camera"),
-    "bunny": ("bunny_diffuse", 1920, 1080, 30, 10, (160, 90, 4),
+    "bunny": ("bunny_diffuse", 1920, 1080, 30, 10, (240, 135, 8),
               "bunny.obj 644 triangles brute force, smooth vertex normals, checker ground sphere"),
     "cloth": ("cloth_bunny", 1920, 1080, 64, 10, (160, 90, 4),
               "textured bunny + UV-mapped picnic cloth (no strength maps: the reference has none)"),
