@@ -148,8 +148,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
     };
 
-    long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long born = WRT_CLOCK();
+    [[maybe_unused]] long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] const long long born = WRT_CLOCK();
     while (true) {
         long long since = WRT_CLOCK();
         // ---- (a) segments that have seen every group: shade, scatter or end --

@@ -4,9 +4,12 @@
 // -ffp-contract=off and every expression below is written in the reference's
 // own association order, so float32 results are the ones numpy produces
 // (numpy's einsum sums three float32 products left to right without fused
-// multiply-adds; its float64 contiguous kernel sums (p0 + p2) + p1).  Fast
-// approximations (v_rcp_f32) are used only as conservative pre-filters that
-// decide whether the exact evaluation has to run for a wavefront.
+// multiply-adds; its float64 contiguous kernel sums (p0 + p2) + p1).  Those
+// functions (sphere_discriminant, sphere_root, triangle_terms, triangle_exact,
+// cull_pass, disk_hit, shade_record, scatter_one) produce every number that
+// reaches a result.  Fused multiply-adds and fast approximations (v_rcp_f32)
+// appear only in the conservative tests of the group loops, which decide
+// which (ray, primitive) pairs those functions have to look at.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -259,7 +262,6 @@ __device__ __forceinline__ bool disk_hit(const Ray& r, const float c[4], const f
 // repeats the first.
 struct SpherePair { f32x2 cx, cy, cz, r2; };                          // 2 x f32x4
 struct TriPair { f32x2 p0x, p0y, p0z, ax, ay, az, bx, by, bz; };      // 5 x f32x4 (last two floats unused)
-enum { SPHERE_PAIR_VECS = 2, TRIANGLE_PAIR_VECS = 5 };
 
 // Scalar loads return out of order, so the only usable wait is "all of them".
 // The loops below therefore keep exactly one record fetch in flight: they wait
@@ -563,7 +565,6 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 // whose group has edges too large for E_det <= 5e-6 makes its wavefront fall
 // back to the loop above.
 struct BoundPair { f32x2 cx, cy, cz, r, nx, ny, nz; };                // 4 x f32x4 (last two floats unused)
-enum { BOUND_PAIR_VECS = 4 };
 __device__ __forceinline__ BoundPair fetch_bound_pair(const WRT_CONST f32x4* p) {
     const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
     return BoundPair{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}, {v[12], v[13]}};
