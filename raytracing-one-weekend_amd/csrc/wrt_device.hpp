@@ -863,6 +863,16 @@ __device__ __forceinline__ bool odd_cell(double value) {
     return (f - 2.0 * floor(f * 0.5)) != 0.0;
 }
 
+// x ** 5 as numpy evaluates it for a float64 array (materials.py:369): pow(x, 5.0), which the C
+// library rounds correctly but for a vanishing share of arguments.  The product is carried in
+// two doubles (error-free products through fma) and rounded once.
+__device__ __forceinline__ double fifth_power(double x) {
+    const double h2 = x * x, l2 = __builtin_fma(x, x, -h2);
+    const double h4 = h2 * h2, l4 = __builtin_fma(h2, h2, -h4) + 2.0 * (h2 * l2);
+    const double h5 = h4 * x, l5 = __builtin_fma(h4, x, -h5) + l4 * x;
+    return h5 + l5;
+}
+
 // <Material>.scatter (materials.py) for one hit, float64 where main.render()'s
 // float64 hit arrays make the reference evaluate in float64.
 __device__ __forceinline__ void scatter_one(SceneArg S, const MaterialRec& M, const PathKey& key,
@@ -934,8 +944,7 @@ __device__ __forceinline__ void scatter_one(SceneArg S, const MaterialRec& M, co
         const bool cannot = ((double)ratio * sin_t) > 1.0;
         float r0 = (1.0f - ratio) / (1.0f + ratio);
         r0 = r0 * r0;
-        const double m = 1.0 - cos_t, m2 = m * m;
-        const double reflectance = (double)r0 + (double)(1.0f - r0) * (m2 * m2 * m);
+        const double reflectance = (double)r0 + (double)(1.0f - r0) * fifth_power(1.0 - cos_t);
         uint32_t r[4];
         keyed_words(key, PURPOSE_SCHLICK, bounce, 0, r);
         const bool reflect = cannot || (reflectance > unit_interval(r[0]));

@@ -106,10 +106,7 @@ def test_scatter_against_reference(ctx):
         assert np.array_equal(col, f[name + "_colours"]), name
         want = f[name + "_dirs"]
         same = np.all(d == want, axis=1)
-        # float64 scatter arithmetic rounded once to float32: at most 1 ulp apart in rare rows
-        # (the Schlick polynomial is evaluated as x*x*x*x*x instead of pow(x, 5))
-        assert same.mean() > 0.995, (name, same.mean())
-        assert np.allclose(d, want, rtol=0, atol=2e-7), name
+        assert same.all(), (name, same.mean())
 
 
 def frame_parity(name, size_override=None):
@@ -132,19 +129,13 @@ def test_whole_frame_against_reference(name):
     f, r = frame_parity(name)
     same_path = np.all(r["path_colours"] == f["path_colours"], axis=1)
     same_segs = r["segments"] == f["segments"]
-    # Paths are chaotic: one float64 rounding that differs (Schlick polynomial) can send a path
-    # elsewhere.  Required: >= 99.5 % of paths bit-identical, image PSNR >= 40 dB and MAE <= 2e-3
-    # on the sqrt-gamma image.
-    assert same_path.mean() >= 0.995, (name, same_path.mean())
-    assert same_segs.mean() >= 0.995, (name, same_segs.mean())
-    assert helpers.psnr(r["image"], f["image"]) >= 40.0, (name, helpers.psnr(r["image"], f["image"]))
-    assert helpers.mae(r["image"], f["image"]) <= 2e-3
-    total = f["counts"][:-1].sum()
-    assert abs(int(r["counts"][:-1].sum()) - int(total)) <= max(2, 0.002 * total)
-    if same_path.all():
-        assert np.array_equal(r["counts"], f["counts"])
-        assert np.array_equal(r["sample_sum"], f["sample_sum"])
-        assert np.array_equal(r["image"], f["image"])
+    # Required: every path, the per-bounce ray counts, the sample sums and the image bit-identical to what the
+    # reference produced (the stated image tolerance, PSNR >= 40 dB and MAE <= 2e-3, follows trivially)
+    assert same_path.all(), (name, same_path.mean())
+    assert same_segs.all(), (name, same_segs.mean())
+    assert np.array_equal(r["counts"], f["counts"])
+    assert np.array_equal(r["sample_sum"], f["sample_sum"])
+    assert np.array_equal(r["image"], f["image"], equal_nan=True)
 
 
 def test_render_matches_oracle_on_fresh_seeds():
@@ -158,7 +149,7 @@ def test_render_matches_oracle_on_fresh_seeds():
     want = numpy_path.render(flat, w, h, s, b, seed=987654321, s_begin=5)
     got = main.render_frame(objs, w, h, s, b, seed=987654321, s_begin=5, want_paths=True)
     same = np.all(got["path_colours"] == want["path_colours"], axis=1)
-    assert same.mean() >= 0.995
+    assert same.all()
     assert helpers.psnr(got["image"], want["image"]) >= 40.0
     assert got["stats"]["paths"] == w * h * s
     assert got["stats"]["sphere_pairs"] == int(got["counts"][:-1].sum()) * 191

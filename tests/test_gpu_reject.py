@@ -109,7 +109,7 @@ def test_reject_on_scaled_meshes_matches_oracle(scale, offset, falls_back):
     assert (st_on["triangle_evaluations"] == 0) == falls_back
     want = numpy_path.render(scene, w, h, s, b, seed=11)
     same = np.all(p_on[:, :3] == want["path_colours"], axis=1)
-    assert same.mean() >= 0.995, same.mean()
+    assert same.all(), same.mean()
 
 
 def test_reruns_are_bit_identical():
