@@ -98,3 +98,22 @@ def test_bunny_scene_full_size():
     segments = int(stats["rays_per_bounce"][:b].sum())
     assert stats["cull_tests"] == segments and stats["sphere_pairs"] == segments
     assert stats["triangle_pairs"] % 644 == 0 and 0 < stats["triangle_pairs"] <= segments * 644
+
+
+@pytest.mark.parametrize("scene_name,size", [
+    ("numpy_one_weekend_demo_scene", (320, 180, 10, 5)),         # the reference's own CPU-runnable configuration
+    ("numpy_glass_experiment_scene", (320, 180, 6, 12)),         # nested glass: long refraction chains
+])
+def test_sphere_configurations_every_path(scene_name, size):
+    """Small enough for the CPU oracle to trace in full: every path, count and pixel must be equal."""
+    from weekend_raytracer import _flatten, main, scenes
+    w, h, s, b = size
+    with contextlib.redirect_stdout(io.StringIO()):
+        objs = getattr(scenes, scene_name)(w / h)
+    got = main.render_frame(objs, w, h, s, b, seed=4321, want_paths=True)
+    flat = _flatten.flatten(*objs, main.HORIZON_COLOUR, main.SKY_COLOUR)
+    want = numpy_path.render(flat, w, h, s, b, 4321)
+    assert np.array_equal(got["path_colours"], want["path_colours"])
+    assert np.array_equal(got["segments"], want["segments"])
+    assert np.array_equal(got["counts"], want["counts"])
+    assert np.array_equal(got["image"], want["image"], equal_nan=True)
