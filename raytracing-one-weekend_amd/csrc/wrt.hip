@@ -136,6 +136,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
 
     int state = LANE_DEAD;
     int g = 0;                         // next group of the current segment
+    unsigned pending = 0u;             // large groups (by slot) the segment still has to go through, in any order
     Closest best = {sentinel, -1, -1};
     PathKey key;
     key.k0 = k0; key.k1 = k1; key.x = key.y = key.s = 0;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     while (true) {
         long long since = WRT_CLOCK();
         // ---- (a) segments that have seen every group: shade, scatter or end --
-        if (state == LANE_ADVANCE && g == n_groups) {
+        if (state == LANE_ADVANCE && g == n_groups && pending == 0u) {
             const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
             SceneArg S = L.S;
             const WRT_CONST RenderArgs& A = L.A;
@@ -266,9 +267,12 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             if (adv) {
                 const GroupRec& G = S.groups[g];
                 type = G.type; first = G.first; count = G.count;
+                const int slot = G.slot;
                 if (type == GROUP_TRIANGLES) {
                     if (!cull_pass(ray, G.c[0], G.c[1], G.c[2], G.c[3])) {
                         ++g; count = 0;                       // culled: next group
+                    } else if (slot >= 0) {
+                        pending |= 1u << slot; ++g; count = 0;
                     } else if (count > CHEAP_GROUP_MAX) {
                         state = LANE_PARKED; count = 0;
                     } else {
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                         ++g;
                     }
                 } else if (type == GROUP_SPHERES) {
-                    if (count > CHEAP_GROUP_MAX) {
+                    if (slot >= 0) {
+                        pending |= 1u << slot; ++g; count = 0;
+                    } else if (count > CHEAP_GROUP_MAX) {
                         state = LANE_PARKED; count = 0;
                     } else {
                         small = true;
@@ -299,51 +305,79 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         }
         WRT_TALLY(6, since);
         // ---- (d) run one large group's loop when it pays ---------------------
-        const unsigned long long parked = __ballot(state == LANE_PARKED);
-        const bool more_cheap = (__ballot(state == LANE_ADVANCE) != 0ull) ||
-                                ((__ballot(state == LANE_DEAD) != 0ull) && !drained);
-        if (parked == 0ull) {
-            if (!more_cheap) break;
-            continue;
+        // Large groups have a slot each (the first 32 of a scene): a segment notes the ones it has to
+        // go through and takes part whenever one of them is run, in any order; the tie rule of the
+        // exact evaluation (earlier group wins equal t) does not depend on the order.  Further large
+        // groups are gone through in scene order: the lane parks at them.
+        // After a slot's loop the wave looks for another slot with enough takers before it goes back
+        // to shading: lanes that still had a cheap loop to go through stay in step with the others.
+        bool finished = false;
+        for (;;) {
+            const unsigned long long parked = __ballot(state == LANE_PARKED);
+            const unsigned long long waiting = __ballot(pending != 0u);
+            const bool more_cheap = (__ballot(state == LANE_ADVANCE && pending == 0u) != 0ull) ||
+                                    ((__ballot(state == LANE_DEAD) != 0ull) && !drained);
+            if (parked == 0ull && waiting == 0ull) { finished = !more_cheap; break; }
+            // the slot with the most takers among those with enough of them (any number is enough
+            // when nothing else can make progress)
+            int run_g = -1, run_n = 0, run_slot = -1;
+            const WRT_CONST int* slots = as_uniform(S.slot_group);
+            const int n_slots = S.n_slots;
+            for (int k = 0; k < n_slots; ++k) {
+                const int n = (int)__popcll(__ballot(((pending >> k) & 1u) != 0u));
+                long long need = 64 - (64ll * TRIP_COST) / slots[32 + k];
+                need = need < 8 ? 8 : need;
+                if (n > run_n && (n >= need || !more_cheap)) { run_n = n; run_slot = k; }
+            }
+            if (run_slot >= 0) {
+                run_g = slots[run_slot];
+            } else {
+                // the group most lanes are parked at (at most four candidates looked at)
+                unsigned long long rest = parked;
+                for (int k = 0; k < 4 && rest != 0ull; ++k) {
+                    const int cand = __builtin_amdgcn_readlane(g, (int)__builtin_ctzll(rest));
+                    const unsigned long long same = __ballot(state == LANE_PARKED && g == cand);
+                    const int n = (int)__popcll(same);
+                    if (n > run_n) { run_n = n; run_g = cand; }
+                    rest &= ~same;
+                }
+                if (run_g < 0) break;                 // only slots without enough takers yet
+            }
+            const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
+            const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
+            const WRT_CONST f32x4* records = as_uniform(S.pairs) + ugroups[run_g].pair_base;
+            if (run_slot < 0 && more_cheap) {
+                const long long loop_cost = (long long)count * (type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
+                long long need = 64 - (64ll * TRIP_COST) / loop_cost;
+                need = need < 8 ? 8 : need;
+                if (run_n < need) break;
+            }
+            const bool mine = run_slot >= 0 ? ((pending >> run_slot) & 1u) != 0u
+                                            : (state == LANE_PARKED) && (g == run_g);
+            since = WRT_CLOCK();
+            if (type == GROUP_TRIANGLES) {
+                pc.triangle += (unsigned long long)run_n * (unsigned)count;
+                pc.triangle_slots += 64ull * (unsigned)count;
+                const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach);
+                if (S.prefilter && __ballot(!k.usable) == 0ull)
+                    loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count,
+                                             k, ray, t_min, t_max, queue, best, pc.triangle_exact);
+                else
+                    loop_triangles(S, records, run_g, first, count, mine, ray, t_min, t_max, queue, best);
+                WRT_TALLY(2, since);
+            } else {
+                pc.sphere += (unsigned long long)run_n * (unsigned)count;
+                pc.sphere_slots += 64ull * (unsigned)count;
+                loop_spheres(S, records, run_g, first, count, mine, ray, t_min, sentinel, queue, best);
+                WRT_TALLY(3, since);
+            }
+            if (run_slot < 0) {                       // a group gone through in scene order: its lanes walk on
+                if (mine) { state = LANE_ADVANCE; ++g; }
+                break;
+            }
+            pending &= ~(1u << run_slot);
         }
-        // the group most lanes are parked at (at most four candidates looked at)
-        int run_g = -1, run_n = 0;
-        unsigned long long rest = parked;
-        for (int k = 0; k < 4 && rest != 0ull; ++k) {
-            const int cand = __builtin_amdgcn_readlane(g, (int)__builtin_ctzll(rest));
-            const unsigned long long same = __ballot(state == LANE_PARKED && g == cand);
-            const int n = (int)__popcll(same);
-            if (n > run_n) { run_n = n; run_g = cand; }
-            rest &= ~same;
-        }
-        const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
-        const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
-        const WRT_CONST f32x4* records = as_uniform(S.pairs) + ugroups[run_g].pair_base;
-        if (more_cheap) {
-            const long long loop_cost = (long long)count * (type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
-            long long need = 64 - (64ll * TRIP_COST) / loop_cost;
-            need = need < 8 ? 8 : need;
-            if (run_n < need) continue;
-        }
-        const bool mine = (state == LANE_PARKED) && (g == run_g);
-        since = WRT_CLOCK();
-        if (type == GROUP_TRIANGLES) {
-            pc.triangle += (unsigned long long)run_n * (unsigned)count;
-            pc.triangle_slots += 64ull * (unsigned)count;
-            const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach);
-            if (S.prefilter && __ballot(!k.usable) == 0ull)
-                loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count, k,
-                                         ray, t_min, t_max, queue, best, pc.triangle_exact);
-            else
-                loop_triangles(S, records, run_g, first, count, mine, ray, t_min, t_max, queue, best);
-            WRT_TALLY(2, since);
-        } else {
-            pc.sphere += (unsigned long long)run_n * (unsigned)count;
-            pc.sphere_slots += 64ull * (unsigned)count;
-            loop_spheres(S, records, run_g, first, count, mine, ray, t_min, sentinel, queue, best);
-            WRT_TALLY(3, since);
-        }
-        if (mine) { state = LANE_ADVANCE; ++g; }
+        if (finished) break;
     }
     // tallies: one atomic per counter per wave
     const WRT_CONST RenderArgs& A = kernel_arguments<RenderLaunch>()->A;
@@ -510,6 +544,7 @@ struct wrt_ctx {
     std::vector<GroupRec> h_groups;
     std::vector<f32x4> h_pairs;
     std::vector<f32x4> h_bounds;
+    std::vector<int> h_slot_group, h_slot_table;
     int triangle_reject = 1;
     MaterialRec h_materials[WRT_MAX_MATERIALS];
     float* d_textures[WRT_MAX_TEXTURES] = {nullptr};
@@ -881,6 +916,25 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     // the loops fetch one step past a group's end: keep that read inside the array
     for (int i = 0; i < 8; ++i) ctx->h_pairs.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
     build_bounds(ctx);
+    // slots of the large groups (see k_render, phase d)
+    ctx->h_slot_group.clear();
+    for (size_t i = 0; i < ctx->h_groups.size(); ++i) {
+        GroupRec& g = ctx->h_groups[i];
+        g.slot = -1;
+        if (g.type != GROUP_DISK && g.count > CHEAP_GROUP_MAX && ctx->h_slot_group.size() < 32) {
+            g.slot = (int)ctx->h_slot_group.size();
+            ctx->h_slot_group.push_back((int)i);
+        }
+    }
+    {   // [0, 32): group index of each slot, [32, 64): estimated wave-instructions of its loop
+        std::vector<int> table(64, 1);
+        for (size_t k = 0; k < ctx->h_slot_group.size(); ++k) {
+            const GroupRec& g = ctx->h_groups[ctx->h_slot_group[k]];
+            table[k] = ctx->h_slot_group[k];
+            table[32 + k] = g.count * (g.type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
+        }
+        ctx->h_slot_table = table;
+    }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_sph = up(ctx->h_sph.size() * sizeof(f32x4) + 16), b_rad = up(ctx->h_sph_radius.size() * 4 + 16),
                  b_smat = up(ctx->h_sph_material.size() + 16), b_tri = up(ctx->h_tri.size() * sizeof(f32x4) + 16),
@@ -889,8 +943,8 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                  b_grp = up(ctx->h_groups.size() * sizeof(GroupRec) + 16), b_mat = up(sizeof(ctx->h_materials)),
                  b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam)),
                  b_pairs = up(ctx->h_pairs.size() * sizeof(f32x4) + 16),
-                 b_bounds = up(ctx->h_bounds.size() * sizeof(f32x4) + 16);
-    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs + b_bounds;
+                 b_bounds = up(ctx->h_bounds.size() * sizeof(f32x4) + 16), b_slots = up(64 * sizeof(int));
+    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs + b_bounds + b_slots;
     if (total > ctx->blob_bytes) {
         if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
@@ -917,6 +971,8 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     S.cam = (const CameraRec*)put(&ctx->h_cam, sizeof(ctx->h_cam), b_cam);
     S.pairs = (const f32x4*)put(ctx->h_pairs.data(), ctx->h_pairs.size() * sizeof(f32x4), b_pairs);
     S.bounds = (const f32x4*)put(ctx->h_bounds.data(), ctx->h_bounds.size() * sizeof(f32x4), b_bounds);
+    S.slot_group = (const int*)put(ctx->h_slot_table.data(), ctx->h_slot_table.size() * sizeof(int), b_slots);
+    S.n_slots = (int)ctx->h_slot_group.size();
     S.n_groups = (int)ctx->h_groups.size();
     HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
     ctx->committed = true;

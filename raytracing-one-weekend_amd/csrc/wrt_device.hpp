@@ -32,12 +32,14 @@ __device__ __forceinline__ const WRT_CONST T* as_uniform(const T* p) {
 enum { GROUP_SPHERES = 0, GROUP_TRIANGLES = 1, GROUP_DISK = 2 };
 enum { PURPOSE_JITTER = 0, PURPOSE_LENS = 1, PURPOSE_UNITVEC = 2, PURPOSE_SCHLICK = 3 };
 
-struct GroupRec {            // 96 bytes, uniform
+struct GroupRec {            // 112 bytes, uniform
     int type, first, count, material;
     int pair_base;           // first f32x4 of this group's component-interleaved pair records
     int bound_base;          // triangles: first f32x4 of the per-triangle bounding records (two triangles per 4 x f32x4)
     float edge_max;          // triangles: largest |component| of any edge vector A, B of the group
     float reach;             // triangles: largest |coordinate| of any corner or bounding-sphere centre
+    int slot;                // large groups: bit of the render kernel's pending mask, -1 = none
+    int pad[3];
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -81,6 +83,8 @@ struct SceneRec {
     const f32x4* pairs;           // sphere and triangle groups again, two primitives per record (group loops)
     const f32x4* bounds;          // per triangle: bounding sphere and B x A, two triangles per record
     int prefilter;                // 1: triangle loops reject by bounding sphere first
+    const int* slot_group;        // [0, 32): group index of each slot, [32, 64): cost estimate of its loop
+    int n_slots;
     float horizon[3], zenith[3];
     int n_groups;
 };
@@ -180,6 +184,14 @@ struct Closest {
 };
 
 struct Ray { float ox, oy, oz, dx, dy, dz; };
+
+// Does a hit at t in group g replace `best`?  main.py:144 replaces on a strictly smaller t while
+// it goes through the groups in order, so of equal t the earlier group stays; written with the
+// group indices, the rule holds whatever order the groups are gone through in.  (Inside a group
+// the candidates come in index order and the first of equal t stays, numpy.argmin.)
+__device__ __forceinline__ bool closer(float t, int g, const Closest& best) {
+    return t < best.t || (t == best.t && g < best.group);
+}
 
 // What the reference would have evaluated, for the roofline accounting
 struct PairCounts { unsigned long long sphere, triangle, cull, disk, sphere_slots, triangle_slots, triangle_exact; };
@@ -390,7 +402,7 @@ __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, i
             float h;
             const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
             const float t = sphere_root(h, disc, t_min, sentinel);
-            if (disc > 0.00001f && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
+            if (disc > 0.00001f && closer(t, g, best)) { best.t = t; best.group = g; best.prim = prim; }
         }
     }
     q.n = 0;
@@ -484,7 +496,7 @@ __device__ __forceinline__ void drain_triangles(SceneArg S, LaneQueue& q, int g,
             const f32x4 a = S.tri[2 * prim], b = S.tri[2 * prim + 1];
             const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, S.tri_bz[prim]);
             float t;
-            if (triangle_exact(terms, w.t_min, w.t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = prim; }
+            if (triangle_exact(terms, w.t_min, w.t_max, t) && closer(t, g, best)) { best.t = t; best.group = g; best.prim = prim; }
         }
     }
     q.n = 0;
@@ -639,7 +651,9 @@ __device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, 
     const int before = upto - mine;
     const int total = __builtin_amdgcn_readlane(upto, 63);
     evaluated += (unsigned)total;
-    const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32);
+    // equal t: an earlier group's hit stays (index field 0 cannot be undercut), a later group's goes
+    const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32) |
+                                     (best.group > g ? 0xffffffffull : 0ull);
     q.share_best[lane] = start;
     for (int chunk = 0; chunk < total; chunk += SHARE_ITEMS) {
         // owners write their items of this chunk, entry by entry, lowest index first

@@ -196,3 +196,53 @@ def test_more_candidates_than_queue_slots(n_spheres, n_triangles):
     same = np.all(out["path_colours"] == ref["path_colours"], axis=1)
     assert same.all(), same.mean()
     assert np.array_equal(out["segments"], ref["segments"])
+
+
+def layered_scene(n_copies, n_per_group, seed):
+    """The same primitives in several large groups with different materials: every hit is a tie
+    between groups, which the earliest group must win whatever order the groups are run in; with
+    more than 32 large groups some of them are gone through in scene order."""
+    rng = np.random.default_rng(seed)
+    materials = {0: dict(kind="diffuse", colour=np.array([0.5, 0.5, 0.5], np.single))}
+    groups = [dict(type="spheres", centres=np.array([[0, -500.5, 0]], np.single), radii=np.array([500.0], np.single),
+                   materials=np.array([0], np.ubyte))]
+    c = rng.uniform(-2, 2, (n_per_group, 3)).astype(np.single) * np.array([1, 0.4, 1], np.single) + np.array([0, 1, 0], np.single)
+    rad = rng.uniform(0.15, 0.4, n_per_group).astype(np.single)
+    p0 = (rng.uniform(-2, 2, (n_per_group, 3)) * np.array([1, 0.4, 1]) + np.array([0, 1.2, 0])).astype(np.single)
+    A = rng.uniform(-0.8, 0.8, (n_per_group, 3)).astype(np.single)
+    B = rng.uniform(-0.8, 0.8, (n_per_group, 3)).astype(np.single)
+    nrm = np.cross(A, B)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1)[:, None]).astype(np.single)
+    uv = np.zeros((n_per_group, 2), np.single)
+    pts = np.concatenate([p0, p0 + A, p0 + B])
+    bc = np.mean(pts, axis=0).astype(np.single)
+    br = np.single(np.max(np.linalg.norm(pts - bc, axis=1)) * 1.01)
+    for k in range(n_copies):
+        m = 1 + k
+        kind = k % 3
+        materials[m] = (dict(kind="diffuse", colour=rng.uniform(0.2, 0.9, 3).astype(np.single)) if kind == 0 else
+                        dict(kind="metal", colour=rng.uniform(0.6, 1, 3).astype(np.single), fuzziness=0.0) if kind == 1
+                        else dict(kind="dielectric", ior=1.5))
+        if k % 2 == 0:
+            groups.append(dict(type="spheres", centres=c.copy(), radii=rad.copy(),
+                               materials=np.full(n_per_group, m, np.ubyte)))
+        else:
+            groups.append(dict(type="triangles", pt0=p0.copy(), A=A.copy(), B=B.copy(), n0=nrm, n1=nrm, n2=nrm, uv0=uv,
+                               uv1=uv, uv2=uv, material_id=m, bounds_centre=bc, bounds_radius=br))
+    cam = numpy_path.camera_basis(np.array([5.0, 2.5, 6.0]), np.array([0.0, 0.9, 0.0]), 8.0, 0.0, 1.6, 45.0)
+    sky = dict(horizon=np.array([1, 1, 1], np.single), zenith=np.array([0.5, 0.7, 1.0], np.single))
+    return dict(camera=cam, groups=groups, materials=materials, sky=sky)
+
+
+@pytest.mark.parametrize("n_copies,n_per_group", [(4, 12), (6, 40), (40, 10)])
+def test_ties_between_large_groups(n_copies, n_per_group):
+    from weekend_raytracer import main
+    scene = layered_scene(n_copies, n_per_group, seed=n_copies)
+    w, h, s, b = 48, 30, 2, 6
+    want = numpy_path.render(scene, w, h, s, b, seed=77)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    got = main.render_frame(objs, w, h, s, b, seed=77, want_paths=True)
+    assert np.array_equal(got["path_colours"], want["path_colours"])
+    assert np.array_equal(got["segments"], want["segments"])
+    assert np.array_equal(got["counts"], want["counts"])
