@@ -37,16 +37,16 @@ static constexpr int SURVIVOR_MARK = 100;
 //
 // The work is cut into 64-path batches (one 8x8 pixel tile at one sample index
 // each) that the resident wavefronts take from a counter as their lanes run
-// dry; every lane carries one path.  A
-// lane's segment walks the scene's groups in order.  Small groups, disks and
-// the bounding-sphere culls are evaluated by the lane on its own; a lane that
-// reaches a large group (many spheres, or a triangle group whose cull it
-// passed) PARKS there.  The expensive wave-uniform loop over a group's
-// primitives runs only when enough lanes are parked at it (or nothing else
-// can make progress), so the loop that dominates the run time executes with
-// nearly full wavefronts even though paths end, miss the cull and get
-// refilled at different times.  Finished segments are shaded, ended paths are
-// written out and their lanes refilled from the wave's current batch.
+// dry; every lane carries one path.  A lane's segment walks the scene's groups
+// once.  Small groups, disks and the bounding-sphere culls are evaluated by the
+// lane on its own; of a large group (many spheres, or a triangle group whose
+// cull the ray passed) the lane only notes that the segment has to go through
+// it.  The expensive wave-uniform loop over a large group's primitives runs
+// when enough lanes are waiting for it (or nothing else can make progress), so
+// the loops that dominate the run time execute with nearly full wavefronts even
+// though paths end, miss culls and get refilled at different times.  Segments
+// that have been through all their groups are shaded, ended paths are written
+// out and their lanes refilled from the wave's current batch.
 enum { LANE_DEAD = 0, LANE_ADVANCE = 1, LANE_PARKED = 2 };
 
 // -DWRT_TIMING=1: every wave tallies where its time goes (wrt_stats.clock_ticks)
