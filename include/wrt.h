@@ -85,7 +85,7 @@ typedef struct wrt_stats {
     uint64_t sphere_lane_slots;
     uint64_t triangle_lane_slots;
     /* clock tallies of the bounce kernel, zero unless the library was built with
-       -DWRT_TIMING=1 (shader clock ticks, 100 MHz): [0] sum of the wavefronts' lifetimes,
+       -DWRT_TIMING=1 (shader clock cycles): [0] sum of the wavefronts' lifetimes,
        [1] longest lifetime, [2] in triangle loops, [3] in sphere loops, [4] shading,
        [5] refilling lanes, [6] per-lane group walk, [7] working candidate queues off
        (part of [2] and [3]) */

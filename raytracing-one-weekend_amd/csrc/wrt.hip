@@ -124,6 +124,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     // the batch this wave is handing out to its lanes and how many of its 64 paths are gone
     long long batch = 0;
     unsigned batch_used = 64;
+    int batch_x0 = 0, batch_y0 = 0, batch_sample = 0;   // its tile's corner pixel and its global sample index
     bool drained = false;              // the launch has no batch left
     int n_groups;
     float sentinel, t_min, t_max;
@@ -213,13 +214,18 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 batch = (long long)(((unsigned long long)hi << 32) | lo);
                 if (batch >= A.n_batches) { drained = true; break; }
                 batch_used = 0;
+                {
+                    const long long tile = batch / A.n_samples;
+                    batch_x0 = (int)(tile % A.tiles_x) * 8;
+                    batch_y0 = (int)(tile / A.tiles_x) * 8;
+                    batch_sample = A.s_begin + (int)(batch - tile * A.n_samples);
+                }
                 if (A.max_bounces != 0) {
                     // every lane makes one ray of the batch, whatever path it carries itself
-                    const long long tile = batch / A.n_samples;
                     PathKey fresh = key;
-                    fresh.x = (uint32_t)((int)(tile % A.tiles_x) * 8 + (int)(lane & 7u));
-                    fresh.y = (uint32_t)((int)(tile / A.tiles_x) * 8 + (int)(lane >> 3));
-                    fresh.s = (uint32_t)(A.s_begin + (int)(batch - tile * A.n_samples));
+                    fresh.x = (uint32_t)(batch_x0 + (int)(lane & 7u));
+                    fresh.y = (uint32_t)(batch_y0 + (int)(lane >> 3));
+                    fresh.s = (uint32_t)batch_sample;
                     if ((int)fresh.x < A.width && (int)fresh.y < A.height) {
                         float o[3], d[3];
                         camera_ray(*S.cam, A.width, A.height, fresh, o, d);
@@ -230,12 +236,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             }
             const unsigned in_tile = batch_used + (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
             if (state == LANE_DEAD && in_tile < 64u) {
-                const long long tile = batch / A.n_samples;
-                const int s_local = (int)(batch - tile * A.n_samples);
-                const int tx = (int)(tile % A.tiles_x), ty = (int)(tile / A.tiles_x);
-                const int x = tx * 8 + (int)(in_tile & 7u), y = ty * 8 + (int)(in_tile >> 3);
+                const int x = batch_x0 + (int)(in_tile & 7u), y = batch_y0 + (int)(in_tile >> 3);
                 if (x < A.width && y < A.height) {
-                    key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)(A.s_begin + s_local);
+                    key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)batch_sample;
                     if (A.max_bounces == 0) {
                         // bounce 0 is already the limit: zeroed untraced (main.py:211-212)
                         f32x4 rec = {0.0f, 0.0f, 0.0f, (float)SURVIVOR_MARK};
