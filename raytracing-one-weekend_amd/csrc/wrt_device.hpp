@@ -269,8 +269,8 @@ __device__ __forceinline__ bool disk_hit(const Ray& r, const float c[4], const f
 // half is an ordinary IEEE multiply or add, so the results are the ones of
 // the one-primitive functions above.  Lanes with `active` false ride along.
 // Lowest index wins equal t (numpy.argmin, sphere_group.py:213,
-// triangle_group.py:399); an earlier group wins equal t (strict <,
-// main.py:144).  A group with an odd count ends in a pair whose second half
+// triangle_group.py:399); an earlier group wins equal t (main.py:144, see
+// closer()).  A group with an odd count ends in a pair whose second half
 // repeats the first.
 struct SpherePair { f32x2 cx, cy, cz, r2; };                          // 2 x f32x4
 struct TriPair { f32x2 p0x, p0y, p0z, ax, ay, az, bx, by, bz; };      // 5 x f32x4 (last two floats unused)
