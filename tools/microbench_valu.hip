@@ -48,6 +48,19 @@ __global__ void k(float* out, long long* cyc, int iters, float seed) {
                 if (MODE == 29) asm volatile("s_mov_b32 s20, s21\n\ts_mov_b32 s22, s23" : : : "s20", "s22");
                 if (MODE == 30) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[(i + 3) & 7]), "s"(pm));
                 if (MODE == 31) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p[i]) : "v"(p[(i + 7) & 7]), "s"(pm));
+                if (MODE == 32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 33) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 34) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "+v"(p[i]) : "v"(m), "v"(c) : "vcc");
+                if (MODE == 35) asm volatile("v_add_f64 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
+                if (MODE == 36) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pm), "v"(pc));
+                if (MODE == 37) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 38) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
+                if (MODE == 39) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(m));
+                if (MODE == 40) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m));
+                if (MODE == 41) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(m));
+                if (MODE == 42) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) : : "vcc");
+                if (MODE == 43) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
+                if (MODE == 44) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(m) : "s20", "s21");
                 if (MODE == 25) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "v"(pm));
             }
         }
@@ -86,6 +99,9 @@ int main() {
     run<23>("pk_mul s+bcast"); run<24>("pk_fma s+b+neg"); run<25>("pk_add neg");
     run<26>("pk_mul+1smov"); run<27>("fma+1smov"); run<28>("pk_mul+2smov"); run<29>("2 smov only");
     run<30>("pk_mul dist3"); run<31>("pk_mul dep chain");
+    run<32>("v_mul_lo_u32"); run<33>("v_mul_hi_u32"); run<34>("v_mad_u64_u32"); run<35>("v_add_f64"); run<36>("v_fma_f64");
+    run<37>("v_xor_b32"); run<38>("v_mul_f64"); run<39>("v_alignbit"); run<40>("v_cndmask");
+    run<41>("cndmask sgpr"); run<42>("v_addc vcc"); run<43>("cmp+cndmask vcc"); run<44>("cmp+cndmask sgpr");
     run<0>("v_fma_f32 again");
     return 0;
 }
