@@ -361,7 +361,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             if (type == GROUP_TRIANGLES) {
                 pc.triangle += (unsigned long long)run_n * (unsigned)count;
                 pc.triangle_slots += 64ull * (unsigned)count;
-                const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach);
+                const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach,
+                                                           ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2]);
                 if (S.prefilter && __ballot(!k.usable) == 0ull)
                     loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count,
                                              k, ray, t_min, t_max, queue, best, pc.triangle_exact);
@@ -808,7 +809,8 @@ int wrt_set_sky(wrt_ctx* ctx, const float horizon[3], const float zenith[3]) {
 
 // Smallest sphere around the corners of each triangle of the large groups and B x A, two
 // triangles per record, padded to whole blocks of 16 with the group's last triangle; the group's
-// largest edge component and largest coordinate for the error bounds of the reject test.
+// largest edge component and largest coordinate offset from the group's bounding-sphere centre for
+// the error bounds of the reject test.
 static void build_bounds(wrt_ctx* ctx) {
     ctx->h_bounds.clear();
     for (GroupRec& g : ctx->h_groups) {
@@ -853,8 +855,8 @@ static void build_bounds(wrt_ctx* ctx) {
             double m = 0.0;
             for (int a = 0; a < 3; ++a) {
                 m = std::max(m, std::max(std::fabs(A[a]), std::fabs(B[a])));
-                for (int k = 0; k < 3; ++k) reach = std::max(reach, std::fabs(V[k][a]));
-                reach = std::max(reach, std::fabs(cd[a]));
+                for (int k = 0; k < 3; ++k) reach = std::max(reach, std::fabs(V[k][a] - (double)g.c[a]));
+                reach = std::max(reach, std::fabs(cd[a] - (double)g.c[a]));
             }
             edge_max = std::max(edge_max, m);
             cx[j] = cf[0]; cy[j] = cf[1]; cz[j] = cf[2];

@@ -37,7 +37,7 @@ struct GroupRec {            // 112 bytes, uniform
     int pair_base;           // first f32x4 of this group's component-interleaved pair records
     int bound_base;          // triangles: first f32x4 of the per-triangle bounding records (two triangles per 4 x f32x4)
     float edge_max;          // triangles: largest |component| of any edge vector A, B of the group
-    float reach;             // triangles: largest |coordinate| of any corner or bounding-sphere centre
+    float reach;             // triangles: largest |coordinate - c| of any corner or bounding-sphere centre
     int slot;                // large groups: bit of the render kernel's pending mask, -1 = none
     int pad[3];
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2
@@ -561,7 +561,10 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 //
 // Safety: the test must keep every pair for which the reference's float32
 // arithmetic reports a hit, rounding errors included.  With u = 2^-24,
-// D = max|d_i|, T >= max|o_i - P0_i|, M = largest edge component, the
+// D = max|d_i|, T >= max|o_i - P0_i| (from the ray origin's offset to the
+// group's bounding-sphere centre and the group's extent about it, so that it
+// does not grow with the scene's distance from the origin), M = largest edge
+// component, the
 // reference's determinant and its u, v numerators differ from their exact
 // values by at most E_det = 32u D M^2 and E = 40u D T M (three-term float32 dot
 // products of two-term cross products).  The reference reports a hit only if
@@ -591,12 +594,15 @@ struct SphereReject {
     bool usable;     // the bounds of the error analysis hold for this lane
     bool active;     // the lane's ray is at this group
 };
-__device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool active, float edge_max, float reach) {
+__device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool active, float edge_max, float reach,
+                                                            float gx, float gy, float gz) {
     SphereReject k;
     k.active = active;
     const float D = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
-    const float O = fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz));
-    const float T = O + reach;
+    // every corner and sphere centre of the group lies within `reach` of (gx, gy, gz) in each
+    // coordinate, so T bounds |o_i - P0_i| and |o_i - c_i| wherever the scene sits
+    const float O = fmaxf(fmaxf(fabsf(r.ox - gx), fabsf(r.oy - gy)), fabsf(r.oz - gz));
+    const float T = (O + reach) * 1.000001f;
     k.dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
     k.widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
     k.slack = active ? 3.9e-6f * k.dd * (3.0f * T * T) + 1.0e-30f : -__builtin_inff();
@@ -787,7 +793,8 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
             if (pass_mask == 0ull) continue;
             pc.triangle += (unsigned long long)__popcll(pass_mask) * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
-            const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach);
+            const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach, groups[g].c[0],
+                                                       groups[g].c[1], groups[g].c[2]);
             if (S.prefilter && __ballot(!k.usable) == 0ull)
                 loop_triangles_rejecting(S, as_uniform(S.bounds) + groups[g].bound_base, g, first, count, k, r, t_min,
                                          t_max, q, best, pc.triangle_exact);

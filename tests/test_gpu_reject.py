@@ -97,6 +97,7 @@ class Flat:
     (1.0, (0.0, 0.0, 0.0), False),
     (0.01, (0.0, 0.0, 0.0), False),
     (1.0, (300.0, -200.0, 150.0), False),      # far from the origin: large coordinates, small triangles
+    (0.06, (8000.0, -3000.0, 500.0), False),   # very far: the reject must neither miss a hit nor give up rejecting
     (30.0, (0.0, 0.0, 0.0), True),             # edges of ~10 units: outside the reject's error bounds
 ])
 def test_reject_on_scaled_meshes_matches_oracle(scale, offset, falls_back):
@@ -107,6 +108,7 @@ def test_reject_on_scaled_meshes_matches_oracle(scale, offset, falls_back):
     (p_on, st_on), (p_off, st_off) = both_ways(objs, w, h, s, b, seed=11)
     assert np.array_equal(p_on.view(np.uint32), p_off.view(np.uint32))
     assert (st_on["triangle_evaluations"] == 0) == falls_back
+    assert st_on["triangle_evaluations"] < 0.3 * st_on["triangle_pairs"]
     want = numpy_path.render(scene, w, h, s, b, seed=11)
     same = np.all(p_on[:, :3] == want["path_colours"], axis=1)
     assert same.all(), same.mean()
