@@ -420,7 +420,7 @@ def mesh_group(ref, obj_name, material_id, smooth=False, use_uvs=True, lift=True
 
 
 def cloth_bunny_scene(ref, aspect_ratio):
-    """BASELINE config 4 without strength maps (the reference has no such
+    """The textured-bunny-and-cloth benchmark configuration without strength maps (the reference has no such
     material): the shipped textured bunny scene (scenes.py:563-661) plus
     smallCloth.obj UV-mapped with picnicCloth.jpg."""
     cam, groups, material_map = ref.scenes.ray_group_triangle_group_bunny_scene(aspect_ratio)
@@ -430,7 +430,7 @@ def cloth_bunny_scene(ref, aspect_ratio):
 
 
 def bunny_diffuse_scene(ref, aspect_ratio):
-    """BASELINE config 3: the bunny scene with the texture swapped for the
+    """The mesh benchmark configuration: the bunny scene with the texture swapped for the
     Lambertian `bunny_mat` the scene defines but leaves unused (scenes.py:584-586)."""
     cam, groups, material_map = ref.scenes.ray_group_triangle_group_bunny_scene(aspect_ratio)
     material_map[1] = ref.materials.Diffuse(numpy.array([0.2, 0.7, 0.1], dtype=numpy.single))

@@ -80,7 +80,7 @@ def check_full_frame(flat, p, a, stats, w, h, s, b, seed, n_groups_pairs):
 
 
 def test_cover_scene_full_size():
-    """BASELINE config 2: 484 spheres, depth of field, 1280x720, 100 spp."""
+    """The sphere benchmark configuration: 484 spheres, depth of field, 1280x720, 100 spp."""
     from weekend_raytracer import scenes
     w, h, s, b, seed = 1280, 720, 100, 10, 1234
     flat, p, a, stats = full_frame(lambda ar: scenes.cover_scene(ar, scenes.sphere_field_records(480)),
@@ -90,7 +90,7 @@ def test_cover_scene_full_size():
 
 
 def test_bunny_scene_full_size():
-    """BASELINE config 3: bunny.obj brute force, smooth normals, 1920x1080, 30 spp, 10 bounces."""
+    """The mesh benchmark configuration: bunny.obj, every ray against every triangle, smooth normals, 1920x1080, 30 spp, 10 bounces."""
     from weekend_raytracer import scenes
     w, h, s, b, seed = 1920, 1080, 30, 10, 1234
     flat, p, a, stats = full_frame(scenes.bunny_diffuse_scene, w, h, s, b, seed)
