@@ -1,6 +1,7 @@
 // libwrt.so: kernels and the C ABI (include/wrt.h).  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             } else {
                 pc.sphere += (unsigned long long)run_n * (unsigned)count;
                 pc.sphere_slots += 64ull * (unsigned)count;
-                loop_spheres(S, records, run_g, first, count, mine, ray, t_min, sentinel, queue, best);
+                loop_spheres(S, records, run_g, first, count, mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1],
+                             ugroups[run_g].c[2], t_min, sentinel, queue, best);
                 WRT_TALLY(3, since);
             }
             if (run_slot < 0) {                       // a group gone through in scene order: its lanes walk on
@@ -893,6 +895,15 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     ctx->h_pairs.clear();
     for (GroupRec& g : ctx->h_groups) {
         g.pair_base = (int)ctx->h_pairs.size();
+        if (g.type == GROUP_SPHERES) {
+            // the loops' reference point: the median centre (a ground sphere far below does not move it)
+            for (int ax = 0; ax < 3; ++ax) {
+                std::vector<float> v((size_t)g.count);
+                for (int j = 0; j < g.count; ++j) v[(size_t)j] = ctx->h_sph[(size_t)g.first + j][ax];
+                std::nth_element(v.begin(), v.begin() + g.count / 2, v.end());
+                g.c[ax] = v[(size_t)(g.count / 2)];
+            }
+        }
         if (g.type == GROUP_DISK) continue;
         // whole pairs; the filler repeats the last primitive
         const int padded = (g.count + 1) & ~1;
@@ -900,12 +911,23 @@ int wrt_scene_commit(wrt_ctx* ctx) {
             const size_t a = (size_t)g.first + (j < g.count ? j : g.count - 1),
                          b = (size_t)g.first + (j + 1 < g.count ? j + 1 : g.count - 1);
             if (g.type == GROUP_SPHERES) {
-                // radius^2 a little large: the loops compute an upper bound of the discriminant
-                const f32x4 sa = ctx->h_sph[a], sb = ctx->h_sph[b];
-                const float wa = std::nextafter((float)((double)sa.w * (1.0 + 4e-7)), INFINITY),
-                            wb = std::nextafter((float)((double)sb.w * (1.0 + 4e-7)), INFINITY);
-                ctx->h_pairs.push_back(f32x4{sa.x, sb.x, sa.y, sb.y});
-                ctx->h_pairs.push_back(f32x4{sa.z, sb.z, wa, wb});
+                // (c - g, |c - g|^2 - r''^2) about the group's median centre g; r''^2 = r^2 (1 + 1.6e-5):
+                // the loops compute an upper bound of the discriminant in expanded form
+                const f32x4 sv[2] = {ctx->h_sph[a], ctx->h_sph[b]};
+                float rel[2][4];
+                for (int h = 0; h < 2; ++h) {
+                    double cs2 = 0.0;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        rel[h][ax] = (float)((double)sv[h][ax] - (double)g.c[ax]);
+                        cs2 += (double)rel[h][ax] * (double)rel[h][ax];
+                    }
+                    // the rounding of c - g moves the sphere by at most u |c - g| per coordinate: widen r for it
+                    const double r = std::sqrt((double)sv[h].w) + 1.1e-7 * std::sqrt(cs2);
+                    rel[h][3] = (float)(cs2 - r * r * (1.0 + 1.6e-5));
+                    rel[h][3] = std::nextafter(rel[h][3], -INFINITY);          // k a little small = r''^2 a little large
+                }
+                ctx->h_pairs.push_back(f32x4{rel[0][0], rel[1][0], rel[0][1], rel[1][1]});
+                ctx->h_pairs.push_back(f32x4{rel[0][2], rel[1][2], rel[0][3], rel[1][3]});
             } else {
                 // (P0, A.x) (A.yz, B.xy) B.z -> P0x P0y | P0z Ax | Ay Az | Bx By | Bz
                 const f32x4 a0 = ctx->h_tri[2 * a], a1 = ctx->h_tri[2 * a + 1], b0 = ctx->h_tri[2 * b],

@@ -40,7 +40,7 @@ struct GroupRec {            // 112 bytes, uniform
     float reach;             // triangles: largest |coordinate - c| of any corner or bounding-sphere centre
     int slot;                // large groups: bit of the render kernel's pending mask, -1 = none
     int pad[3];
-    float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2
+    float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
     float v[4];              // disk: V / radius
@@ -314,19 +314,26 @@ __device__ __forceinline__ Ray2 both_halves(const Ray& r) {
     return Ray2{{r.ox, r.ox}, {r.oy, r.oy}, {r.oz, r.oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}};
 }
 
-// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres
-// in 12 packed instructions; it only has to be safe, so the dot products are fused.  With
-// u = 2^-24, co = o - c as rounded by both evaluations and cc = |co|^2, the reference's
-// float32 value is within (8.1 |d|^2 + 5) u cc + 2u r^2 of the exact h^2 - (cc - r^2), the
-// fused one within (7.1 |d|^2 + 5) u cc + 2u r'^2 of h^2 + r'^2 - cc.  The pair records carry
-// r'^2 = r^2 (1 + 4e-7) and `widen` = 17u (|d|^2 + 1), which covers the difference.
-__device__ __forceinline__ f32x2 sphere_discriminant_bound2(const Ray2& r, const SpherePair& s, float widen) {
-    const f32x2 cox = r.ox - s.cx, coy = r.oy - s.cy, coz = r.oz - s.cz;
-    const f32x2 h = __builtin_elementwise_fma(r.dz, coz, __builtin_elementwise_fma(r.dy, coy, r.dx * cox));
-    const f32x2 cc = __builtin_elementwise_fma(coz, coz, __builtin_elementwise_fma(coy, coy, cox * cox));
-    const f32x2 disc = __builtin_elementwise_fma(h, h, s.r2 - cc);
-    const f32x2 w = {widen, widen};
-    return __builtin_elementwise_fma(w, cc, disc);
+// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres in 10
+// packed instructions.  It only has to be safe, so it is computed in expanded form about a point
+// g of the group (the median sphere centre): with o' = o - g per lane and c' = c - g per sphere,
+//     (d.co)^2 - |co|^2 + r^2  =  (d.o' - d.c')^2 + 2 o'.c' - (|o'|^2 + |c'|^2 - r^2)
+// where d.o' and |o'|^2 are per-lane numbers and k = |c'|^2 - r''^2 is a per-sphere number (the
+// pair records carry c' and k).  Error budget, u = 2^-24, S = |o'| + |c'|:  the reference's float32
+// value exceeds the exact expression of its rounded co by at most (8.1 |d|^2 + 5) u S^2 + 2u r^2;
+// the rounded co, o' and c' move the exact expression by at most 4u (|d|^2 + 1) S^2; the fused
+// evaluation below is within (13 |d|^2 + 8.5) u S^2 + 5u r^2 of its own exact value.  With
+// S^2 <= 2 (|o'|^2 + |c'|^2) the three together are below kappa (|o'|^2 + |c'|^2) + 7u r^2 for
+// kappa = (52 |d|^2 + 37) u, which the bound adds by shrinking (|o'|^2 + k) by (1 - kappa) and by
+// r''^2 = r^2 (1 + 1.6e-5) (enough for |d|^2 <= 4; lanes with longer directions look at every sphere).
+struct SphereBoundRay { f32x2 ox, oy, oz, dx, dy, dz, d_o, oo, keep; };   // each number in both halves
+__device__ __forceinline__ f32x2 sphere_discriminant_bound2(const SphereBoundRay& r, const SpherePair& s) {
+    const f32x2 h = __builtin_elementwise_fma(-r.dz, s.cz, __builtin_elementwise_fma(-r.dy, s.cy,
+                        __builtin_elementwise_fma(-r.dx, s.cx, r.d_o)));
+    const f32x2 t = __builtin_elementwise_fma(r.oz, s.cz, __builtin_elementwise_fma(r.oy, s.cy, r.ox * s.cx));
+    const f32x2 two = {2.0f, 2.0f};
+    const f32x2 m = __builtin_elementwise_fma(two, t, -((r.oo + s.r2) * r.keep));   // s.r2 holds k here
+    return __builtin_elementwise_fma(h, h, m);
 }
 
 // Candidates of the vote are not evaluated on the spot: a hit is rare for one
@@ -413,24 +420,29 @@ __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, i
 
 // one vote for two spheres; the lanes that have to look at one note it down
 // (index + 1 == count: the second half repeats the group's last sphere and is left out)
-__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int count, float thr, float widen,
-                                            const Ray2& r2, LaneQueue& q) {
-    const f32x2 d = sphere_discriminant_bound2(r2, s, widen);
+__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int count, float thr,
+                                            const SphereBoundRay& r2, LaneQueue& q) {
+    const f32x2 d = sphere_discriminant_bound2(r2, s);
     if (__ballot(fmaxf(d.x, d.y) > thr) != 0ull) {
         push(q, d.x > thr, index);
         push(q, d.y > thr && index + 1 < count, index + 1);
     }
 }
 
-// `records`: the group's sphere pairs, 2 x f32x4 each
+// `records`: the group's sphere pairs, 2 x f32x4 each: (c - g, |c - g|^2 - r''^2) of two spheres;
+// (gx, gy, gz) = g
 __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
-                                             int count, bool active, const Ray& r, float t_min, float sentinel,
-                                             LaneQueue& q, Closest& best) {
-    // inactive lanes can never pass the discriminant test; the threshold leaves room for the
-    // rounding of the bound's last operation
-    const float thr = active ? 0.00000999999f : __builtin_inff();
-    const float widen = 1.02e-6f * (((r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz) + 1.0f);
-    const Ray2 r2 = both_halves(r);
+                                             int count, bool active, const Ray& r, float gx, float gy, float gz,
+                                             float t_min, float sentinel, LaneQueue& q, Closest& best) {
+    const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
+    const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
+    const float keep = 1.0f - (3.11e-6f * dd + 2.35e-6f);
+    // lanes that ride along can never pass; lanes outside the bound's assumptions (or with a NaN
+    // somewhere) always do; the threshold leaves room for the rounding of the bound's last operation
+    const float thr = !active ? __builtin_inff() : (dd <= 4.0f ? 0.00000999999f : -__builtin_inff());
+    const SphereBoundRay r2 = {{ox, ox}, {oy, oy}, {oz, oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz},
+                               {d_o, d_o}, {oo, oo}, {keep, keep}};
     const int pairs = (count + 1) >> 1;
     SphereQuad A = fetch_sphere_quad(records), B;
     int j = 0;
@@ -439,23 +451,23 @@ __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* 
         if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
         WRT_PIN();
-        sphere_step(A.a, 2 * j, count, thr, widen, r2, q);
-        sphere_step(A.b, 2 * j + 2, count, thr, widen, r2, q);
+        sphere_step(A.a, 2 * j, count, thr, r2, q);
+        sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
         WRT_SCALAR_LOADS_ARRIVED();
         if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         A = fetch_sphere_quad(records + 8);
         WRT_PIN();
-        sphere_step(B.a, 2 * j + 4, count, thr, widen, r2, q);
-        sphere_step(B.b, 2 * j + 6, count, thr, widen, r2, q);
+        sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
+        sphere_step(B.b, 2 * j + 6, count, thr, r2, q);
         records += 8;
     }
     WRT_SCALAR_LOADS_ARRIVED();
     if (j < pairs) {                       // up to three pairs left: A holds two of them
         if (short_of_room(q, 6)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
-        sphere_step(A.a, 2 * j, count, thr, widen, r2, q);
-        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, count, thr, widen, r2, q);
-        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, count, thr, widen, r2, q);
+        sphere_step(A.a, 2 * j, count, thr, r2, q);
+        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
+        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
     }
     drain_spheres(S, q, g, first, r, t_min, sentinel, best);
 }
@@ -784,8 +796,8 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
         if (type == GROUP_SPHERES) {
             pc.sphere += (unsigned long long)n_live * (unsigned)count;
             pc.sphere_slots += 64ull * (unsigned)count;
-            loop_spheres(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, live, r, t_min, sentinel, q,
-                         best);
+            loop_spheres(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, live, r, groups[g].c[0],
+                         groups[g].c[1], groups[g].c[2], t_min, sentinel, q, best);
         } else if (type == GROUP_TRIANGLES) {
             const bool pass = live && cull_pass(r, groups[g].c[0], groups[g].c[1], groups[g].c[2], groups[g].c[3]);
             const unsigned long long pass_mask = __ballot(pass);

@@ -1,0 +1,18 @@
+"""SHA-256 of every path record of a workload's frame: two library builds (WRT_LIB=...) that are
+meant to give the same results must print the same sums.
+
+    WRT_LIB=raytracing-one-weekend_amd/lib/libwrt_other.so python tools/frame_checksum.py cover bunny
+"""
+import sys, hashlib
+sys.path.insert(0, "."); sys.path.insert(0, "raytracing-one-weekend_amd")
+import torch, bench
+from weekend_raytracer import main as wr_main
+for name in sys.argv[1:]:
+    kind, width, height, spp, bounces, _, desc = bench.WORKLOADS[name]
+    if name == "cow_teapot": width, height, spp = 960, 540, 4
+    frame = wr_main.Frame(bench.build_scene(kind, width / height), device=0)
+    paths = torch.full((width * height * spp, 4), -7.0, dtype=torch.float32, device="cuda")
+    frame.accumulate(width, height, 0, spp, bounces, 1234, paths=paths)
+    torch.cuda.synchronize()
+    print(name, hashlib.sha256(paths.cpu().numpy().tobytes()).hexdigest()[:24], flush=True)
+    frame.ctx.close()
