@@ -130,3 +130,46 @@ def test_reruns_are_bit_identical():
     frame.ctx.close()
     for p, a in runs[1:]:
         assert np.array_equal(p, runs[0][0]) and np.array_equal(a, runs[0][1])
+
+
+def sphere_scene(scale, offset, n=60, seed=4):
+    """One large sphere group holding small spheres, a few huge ones and the ground, about `offset`."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-3, 3, (n, 3)) * np.array([1, 0.3, 1]) + np.array([0, 0.6, 0])
+    r = rng.uniform(0.1, 0.5, n)
+    c[0], r[0] = (0.0, -1000.0, 0.0), 1000.0                 # ground, inside the same group
+    c[1], r[1] = (0.0, 0.0, -30.0), 25.0                     # a big one behind
+    c[2], r[2] = (0.2, 0.9, 0.3), 0.9                        # one the others are partly inside of
+    centres = (c * scale + offset).astype(np.single)
+    radii = (r * scale).astype(np.single)
+    mats = (np.arange(n) % 3).astype(np.ubyte)
+    materials = {0: dict(kind="diffuse", colour=np.array([0.6, 0.5, 0.4], np.single)),
+                 1: dict(kind="dielectric", ior=1.5),
+                 2: dict(kind="metal", colour=np.array([0.9, 0.9, 0.9], np.single), fuzziness=0.2)}
+    cam = numpy_path.camera_basis(np.array([4.0, 2.0, 7.0]) * scale + offset, np.array([0.0, 0.6, 0.0]) * scale + offset,
+                                  8.0 * scale, 0.1 * scale, 1.5, 45.0)
+    sky = dict(horizon=np.array([1, 1, 1], np.single), zenith=np.array([0.5, 0.7, 1.0], np.single))
+    return dict(camera=cam, groups=[dict(type="spheres", centres=centres, radii=radii, materials=mats)],
+                materials=materials, sky=sky)
+
+
+@pytest.mark.parametrize("scale,offset", [
+    (1.0, (0.0, 0.0, 0.0)),
+    (0.01, (0.0, 0.0, 0.0)),
+    (100.0, (0.0, 0.0, 0.0)),
+    (1.0, (300.0, -200.0, 150.0)),
+    (0.05, (8000.0, -3000.0, 500.0)),
+])
+def test_sphere_bound_on_scaled_scenes_matches_oracle(scale, offset):
+    """The sphere loops vote with an upper bound of the discriminant computed about the group's
+    median centre; it must never miss a sphere the reference's own arithmetic hits."""
+    from weekend_raytracer import main
+    scene = sphere_scene(scale, np.array(offset))
+    w, h, s, b = 64, 40, 3, 8
+    want = numpy_path.render(scene, w, h, s, b, seed=21)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    got = main.render_frame(objs, w, h, s, b, seed=21, want_paths=True)
+    assert np.array_equal(got["path_colours"], want["path_colours"])
+    assert np.array_equal(got["counts"], want["counts"])
+    assert want["counts"][1] > 0.5 * want["counts"][0]
