@@ -911,7 +911,7 @@ int wrt_scene_commit(wrt_ctx* ctx) {
             const size_t a = (size_t)g.first + (j < g.count ? j : g.count - 1),
                          b = (size_t)g.first + (j + 1 < g.count ? j + 1 : g.count - 1);
             if (g.type == GROUP_SPHERES) {
-                // (c - g, |c - g|^2 - r''^2) about the group's median centre g; r''^2 = r^2 (1 + 1.6e-5):
+                // (c - g, k) about the group's median centre g, k = |c - g|^2 (1 - 250u) - r^2 (1 + 2e-6):
                 // the loops compute an upper bound of the discriminant in expanded form
                 const f32x4 sv[2] = {ctx->h_sph[a], ctx->h_sph[b]};
                 float rel[2][4];
@@ -923,8 +923,8 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                     }
                     // the rounding of c - g moves the sphere by at most u |c - g| per coordinate: widen r for it
                     const double r = std::sqrt((double)sv[h].w) + 1.1e-7 * std::sqrt(cs2);
-                    rel[h][3] = (float)(cs2 - r * r * (1.0 + 1.6e-5));
-                    rel[h][3] = std::nextafter(rel[h][3], -INFINITY);          // k a little small = r''^2 a little large
+                    rel[h][3] = (float)(cs2 * (1.0 - 250.0 * 5.9604645e-8) - r * r * (1.0 + 2e-6));
+                    rel[h][3] = std::nextafter(rel[h][3], -INFINITY);          // k a little small: the safe side
                 }
                 ctx->h_pairs.push_back(f32x4{rel[0][0], rel[1][0], rel[0][1], rel[1][1]});
                 ctx->h_pairs.push_back(f32x4{rel[0][2], rel[1][2], rel[0][3], rel[1][3]});

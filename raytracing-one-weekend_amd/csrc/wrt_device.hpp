@@ -314,25 +314,25 @@ __device__ __forceinline__ Ray2 both_halves(const Ray& r) {
     return Ray2{{r.ox, r.ox}, {r.oy, r.oy}, {r.oz, r.oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}};
 }
 
-// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres in 10
+// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres in 8
 // packed instructions.  It only has to be safe, so it is computed in expanded form about a point
 // g of the group (the median sphere centre): with o' = o - g per lane and c' = c - g per sphere,
-//     (d.co)^2 - |co|^2 + r^2  =  (d.o' - d.c')^2 + 2 o'.c' - (|o'|^2 + |c'|^2 - r^2)
-// where d.o' and |o'|^2 are per-lane numbers and k = |c'|^2 - r''^2 is a per-sphere number (the
-// pair records carry c' and k).  Error budget, u = 2^-24, S = |o'| + |c'|:  the reference's float32
-// value exceeds the exact expression of its rounded co by at most (8.1 |d|^2 + 5) u S^2 + 2u r^2;
-// the rounded co, o' and c' move the exact expression by at most 4u (|d|^2 + 1) S^2; the fused
-// evaluation below is within (13 |d|^2 + 8.5) u S^2 + 5u r^2 of its own exact value.  With
-// S^2 <= 2 (|o'|^2 + |c'|^2) the three together are below kappa (|o'|^2 + |c'|^2) + 7u r^2 for
-// kappa = (52 |d|^2 + 37) u, which the bound adds by shrinking (|o'|^2 + k) by (1 - kappa) and by
-// r''^2 = r^2 (1 + 1.6e-5) (enough for |d|^2 <= 4; lanes with longer directions look at every sphere).
-struct SphereBoundRay { f32x2 ox, oy, oz, dx, dy, dz, d_o, oo, keep; };   // each number in both halves
+//     (d.co)^2 - |co|^2 + r^2  =  (d.o' - d.c')^2 + (2 o'.c' - |o'|^2) - (|c'|^2 - r^2)
+// two fused dot-product chains that start from the per-lane numbers d.o' and -|o'|^2, and one
+// per-sphere number k (the pair records carry c' and k).  Error budget, u = 2^-24,
+// S = |o'| + |c'|:  the reference's float32 value exceeds the exact expression of its rounded co by
+// at most (8.1 |d|^2 + 5) u S^2 + 2u r^2; the rounded co, o' and c' move the exact expression by at
+// most 4u (|d|^2 + 1) S^2; the fused evaluation below is within (13 |d|^2 + 11) u S^2 + 3u r^2 of
+// its own exact value.  With S^2 <= 2 (|o'|^2 + |c'|^2) the three together are below
+// kappa (|o'|^2 + |c'|^2) + 5u r^2, kappa = (52 |d|^2 + 42) u.  The lane shrinks its |o'|^2 by
+// (1 - kappa); the record's k = |c'|^2 (1 - 250u) - r^2 (1 + 2e-6) holds the rest for |d|^2 <= 4
+// (lanes with longer directions look at every sphere).
+struct SphereBoundRay { f32x2 ox2, oy2, oz2, dx, dy, dz, d_o, minus_oo; };   // each number in both halves
 __device__ __forceinline__ f32x2 sphere_discriminant_bound2(const SphereBoundRay& r, const SpherePair& s) {
     const f32x2 h = __builtin_elementwise_fma(-r.dz, s.cz, __builtin_elementwise_fma(-r.dy, s.cy,
                         __builtin_elementwise_fma(-r.dx, s.cx, r.d_o)));
-    const f32x2 t = __builtin_elementwise_fma(r.oz, s.cz, __builtin_elementwise_fma(r.oy, s.cy, r.ox * s.cx));
-    const f32x2 two = {2.0f, 2.0f};
-    const f32x2 m = __builtin_elementwise_fma(two, t, -((r.oo + s.r2) * r.keep));   // s.r2 holds k here
+    const f32x2 m = __builtin_elementwise_fma(r.oz2, s.cz, __builtin_elementwise_fma(r.oy2, s.cy,
+                        __builtin_elementwise_fma(r.ox2, s.cx, r.minus_oo))) - s.r2;   // s.r2 holds k here
     return __builtin_elementwise_fma(h, h, m);
 }
 
@@ -429,7 +429,7 @@ __device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int 
     }
 }
 
-// `records`: the group's sphere pairs, 2 x f32x4 each: (c - g, |c - g|^2 - r''^2) of two spheres;
+// `records`: the group's sphere pairs, 2 x f32x4 each: (c - g, k) of two spheres;
 // (gx, gy, gz) = g
 __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
                                              int count, bool active, const Ray& r, float gx, float gy, float gz,
@@ -437,12 +437,13 @@ __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* 
     const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
     const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
     const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
-    const float keep = 1.0f - (3.11e-6f * dd + 2.35e-6f);
+    const float keep = 1.0f - (3.11e-6f * dd + 2.65e-6f);          // 1 - kappa, rounded down
     // lanes that ride along can never pass; lanes outside the bound's assumptions (or with a NaN
     // somewhere) always do; the threshold leaves room for the rounding of the bound's last operation
     const float thr = !active ? __builtin_inff() : (dd <= 4.0f ? 0.00000999999f : -__builtin_inff());
-    const SphereBoundRay r2 = {{ox, ox}, {oy, oy}, {oz, oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz},
-                               {d_o, d_o}, {oo, oo}, {keep, keep}};
+    const float minus_oo = -(oo * keep);
+    const SphereBoundRay r2 = {{2.0f * ox, 2.0f * ox}, {2.0f * oy, 2.0f * oy}, {2.0f * oz, 2.0f * oz},
+                               {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}, {d_o, d_o}, {minus_oo, minus_oo}};
     const int pairs = (count + 1) >> 1;
     SphereQuad A = fetch_sphere_quad(records), B;
     int j = 0;
