@@ -17,7 +17,7 @@ Rank 0 prints ONE JSON line.  `roofline` prices the bounce kernel against the
 FP32 vector peak with the algorithmic flop count of the reference's dense
 evaluation (45 per ray-triangle pair after the cull, 19 per ray-sphere pair,
 14 per bounding-sphere test); `roofline.executed` is the arithmetic the kernel
-really issues for those pairs (a conservative 18-flop bound per sphere pair, a
+really issues for those pairs (a conservative 15-flop bound per sphere pair, a
 28-flop bounding-sphere test per triangle pair, the reference's full
 evaluation only for the pairs that survive).  `--full-evaluation` switches the
 triangle reject off, so that every pair gets the reference's arithmetic.
@@ -91,7 +91,7 @@ def flop_counts(stats):
 
     algorithmic: what the reference evaluates for these pairs (triangle_group.py:289-395 45 flop,
     sphere_group.py:137-205 19 flop, triangle_group.py:158-166 14 flop).  executed: what the kernel
-    issues: spheres meet an 18-flop bound of the discriminant, the full 19 only for candidates (not
+    issues: spheres meet a 15-flop bound of the discriminant, the full 19 only for candidates (not
     counted); triangles of large groups meet a 28-flop bounding-sphere test and the 45-flop evaluation
     only if they survive it; with the reject off (or in small groups) every pair costs 45 + 10 filter flops.
     """
@@ -99,7 +99,7 @@ def flop_counts(stats):
     algorithmic = 45.0 * tri + 19.0 * sph + 14.0 * cull
     evaluated = stats["triangle_evaluations"]
     executed_tri = 28.0 * tri + 45.0 * evaluated if evaluated else 55.0 * tri
-    return algorithmic, executed_tri + 18.0 * sph + 14.0 * cull
+    return algorithmic, executed_tri + 15.0 * sph + 14.0 * cull
 
 
 def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True):
