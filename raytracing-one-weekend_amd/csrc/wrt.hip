@@ -363,7 +363,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 pc.triangle += (unsigned long long)run_n * (unsigned)count;
                 pc.triangle_slots += 64ull * (unsigned)count;
                 const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach,
-                                                           ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2]);
+                                                           ugroups[run_g].radius_max, ugroups[run_g].c[0],
+                                                           ugroups[run_g].c[1], ugroups[run_g].c[2]);
                 if (S.prefilter && __ballot(!k.usable) == 0ull)
                     loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count,
                                              k, ray, t_min, t_max, queue, best, pc.triangle_exact);
@@ -817,7 +818,7 @@ static void build_bounds(wrt_ctx* ctx) {
     ctx->h_bounds.clear();
     for (GroupRec& g : ctx->h_groups) {
         g.bound_base = (int)ctx->h_bounds.size();
-        g.edge_max = 0.0f; g.reach = 0.0f;
+        g.edge_max = 0.0f; g.reach = 0.0f; g.radius_max = 0.0f;
         if (g.type != GROUP_TRIANGLES) continue;
         const int padded = (g.count + 15) & ~15;
         std::vector<float> cx(padded), cy(padded), cz(padded), rr(padded), nx(padded), ny(padded), nz(padded);
@@ -850,8 +851,10 @@ static void build_bounds(wrt_ctx* ctx) {
                     for (int a = 0; a < 3; ++a) c[a] = P[a] + (b2 * nxA[a] + a2 * Bxn[a]) / (2.0 * n2);
                 }
             }
-            const float cf[3] = {(float)c[0], (float)c[1], (float)c[2]};
-            const double cd[3] = {cf[0], cf[1], cf[2]};
+            // stored relative to the group's centre; the sphere's centre is g.c + cf exactly
+            const float cf[3] = {(float)(c[0] - (double)g.c[0]), (float)(c[1] - (double)g.c[1]),
+                                 (float)(c[2] - (double)g.c[2])};
+            const double cd[3] = {(double)g.c[0] + cf[0], (double)g.c[1] + cf[1], (double)g.c[2] + cf[2]};
             double r2 = 0.0;
             for (int k = 0; k < 3; ++k) r2 = std::max(r2, dist2(cd, V[k]));
             double m = 0.0;
@@ -873,8 +876,16 @@ static void build_bounds(wrt_ctx* ctx) {
         }
         g.edge_max = std::nextafter((float)edge_max, INFINITY);
         g.reach = std::nextafter((float)reach, INFINITY);
-        for (int j = 0; j < padded; ++j)   // rounding of the radius itself and the 9e-7 M term of the bound
-            rr[j] = std::nextafter((float)((double)rr[j] * (1.0 + 1e-6) + 1e-6 * edge_max), INFINITY);
+        float radius_max = 0.0f;
+        for (int j = 0; j < padded; ++j) {
+            // rounding of the radius itself and the 9e-7 M term of the bound
+            const float r = std::nextafter((float)((double)rr[j] * (1.0 + 1e-6) + 1e-6 * edge_max), INFINITY);
+            radius_max = std::max(radius_max, r);
+            // the test's constant |c'|^2 - r^2, rounded down
+            const double k = ((double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j]) - (double)r * r;
+            rr[j] = std::nextafter((float)k, -INFINITY);
+        }
+        g.radius_max = radius_max;
         for (int j = 0; j < padded; j += 2) {
             ctx->h_bounds.push_back(f32x4{cx[j], cx[j + 1], cy[j], cy[j + 1]});
             ctx->h_bounds.push_back(f32x4{cz[j], cz[j + 1], rr[j], rr[j + 1]});

@@ -39,7 +39,8 @@ struct GroupRec {            // 112 bytes, uniform
     float edge_max;          // triangles: largest |component| of any edge vector A, B of the group
     float reach;             // triangles: largest |coordinate - c| of any corner or bounding-sphere centre
     int slot;                // large groups: bit of the render kernel's pending mask, -1 = none
-    int pad[3];
+    float radius_max;        // triangles: largest radius of the bounding records
+    int pad[2];
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -594,49 +595,67 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 // 40u |d|^2 |o - c|^2, covered by `slack`.  A lane whose ray is too long or
 // whose group has edges too large for E_det <= 5e-6 makes its wavefront fall
 // back to the loop above.
-struct BoundPair { f32x2 cx, cy, cz, r, nx, ny, nz; };                // 4 x f32x4 (last two floats unused)
+//
+// Like the sphere loops' bound, the test is evaluated in expanded form about the group's
+// bounding-sphere centre g: with o' = o - g per lane and c' = c - g per triangle,
+//     |d|^2 ((r + rho)^2 - |co|^2) + (d.co)^2
+//         = (d.o' - d.c')^2 + |d|^2 ((2 o'.c' - |o'|^2) - (|c'|^2 - r^2) + rho (2 r + rho)),
+// two fused chains from per-lane starts, the per-triangle constant k = |c'|^2 - r^2, and
+// rho (2 r + rho) <= inv (w2 + w3 inv) with inv = 1 / max(|det'|, 1e-5) and the per-lane numbers
+// w2 = 2 r_max widen, w3 = widen^2 (r_max: the group's largest radius).  Its float32 error is at
+// most 30u |d|^2 S^2 + 4u |d|^2 r^2 with S = |o'| + |c'| <= sqrt(3) T: below `slack`.
+struct BoundPair { f32x2 cx, cy, cz, k, nx, ny, nz; };                // 4 x f32x4 (last two floats unused)
 __device__ __forceinline__ BoundPair fetch_bound_pair(const WRT_CONST f32x4* p) {
     const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
     return BoundPair{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}, {v[12], v[13]}};
 }
 
 struct SphereReject {
-    float dd;        // |d|^2
-    float widen;     // 2 * 208u D M^2 (T + M), rounded up
-    float slack;     // float32 error allowance of the squared-distance test; -inf for lanes that ride along
+    f32x2 ox2, oy2, oz2, dx, dy, dz;   // 2 o' and d, each number in both halves
+    f32x2 d_o, minus_oo;               // d.o', -|o'|^2
+    f32x2 dd;                          // |d|^2
+    f32x2 w2, w3;                      // 2 r_max widen and widen^2, widen = 2 * 208u D M^2 (T + M), rounded up
+    f32x2 slack;     // float32 error allowance of the test; -inf for lanes that ride along
     bool usable;     // the bounds of the error analysis hold for this lane
     bool active;     // the lane's ray is at this group
 };
 __device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool active, float edge_max, float reach,
-                                                            float gx, float gy, float gz) {
+                                                            float radius_max, float gx, float gy, float gz) {
     SphereReject k;
     k.active = active;
     const float D = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
     // every corner and sphere centre of the group lies within `reach` of (gx, gy, gz) in each
     // coordinate, so T bounds |o_i - P0_i| and |o_i - c_i| wherever the scene sits
-    const float O = fmaxf(fmaxf(fabsf(r.ox - gx), fabsf(r.oy - gy)), fabsf(r.oz - gz));
+    const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
+    const float O = fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     const float T = (O + reach) * 1.000001f;
-    k.dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
-    k.widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
-    k.slack = active ? 3.9e-6f * k.dd * (3.0f * T * T) + 1.0e-30f : -__builtin_inff();
+    const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
+    const float widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
+    const float w2 = 2.000004f * radius_max * widen, w3 = 1.000004f * widen * widen;
+    const float slack = active ? 3.9e-6f * dd * (3.0f * T * T) + 1.0e-30f : -__builtin_inff();
+    k.ox2 = f32x2{2.0f * ox, 2.0f * ox}; k.oy2 = f32x2{2.0f * oy, 2.0f * oy}; k.oz2 = f32x2{2.0f * oz, 2.0f * oz};
+    k.dx = f32x2{r.dx, r.dx}; k.dy = f32x2{r.dy, r.dy}; k.dz = f32x2{r.dz, r.dz};
+    k.d_o = f32x2{d_o, d_o}; k.minus_oo = f32x2{-oo, -oo}; k.dd = f32x2{dd, dd};
+    k.w2 = f32x2{w2, w2}; k.w3 = f32x2{w3, w3}; k.slack = f32x2{slack, slack};
     // written so that a NaN or infinite ray is not usable
     k.usable = !active || (D * edge_max * edge_max <= 2.5f && T <= 1.0e15f);
     return k;
 }
 
 // sign bit set in a half of the result: the exact evaluation may report a hit
-__device__ __forceinline__ f32x2 sphere_reject2(const Ray2& r, const SphereReject& k, const BoundPair& b) {
-    const f32x2 cox = r.ox - b.cx, coy = r.oy - b.cy, coz = r.oz - b.cz;
-    const f32x2 h = __builtin_elementwise_fma(r.dz, coz, __builtin_elementwise_fma(r.dy, coy, r.dx * cox));
-    const f32x2 cc = __builtin_elementwise_fma(coz, coz, __builtin_elementwise_fma(coy, coy, cox * cox));
+__device__ __forceinline__ f32x2 sphere_reject2(const SphereReject& r, const BoundPair& b) {
+    const f32x2 h = __builtin_elementwise_fma(-r.dz, b.cz, __builtin_elementwise_fma(-r.dy, b.cy,
+                        __builtin_elementwise_fma(-r.dx, b.cx, r.d_o)));
+    const f32x2 m = __builtin_elementwise_fma(r.oz2, b.cz, __builtin_elementwise_fma(r.oy2, b.cy,
+                        __builtin_elementwise_fma(r.ox2, b.cx, r.minus_oo))) - b.k;          // r^2 - |co|^2
     const f32x2 det = __builtin_elementwise_fma(r.dz, b.nz, __builtin_elementwise_fma(r.dy, b.ny, r.dx * b.nx));
     const f32x2 inv = {__builtin_amdgcn_rcpf(fmaxf(fabsf(det.x), 0.00001f)),
                        __builtin_amdgcn_rcpf(fmaxf(fabsf(det.y), 0.00001f))};
-    const f32x2 widen = {k.widen, k.widen}, dd = {k.dd, k.dd}, slack = {k.slack, k.slack};
-    const f32x2 q = __builtin_elementwise_fma(widen, inv, b.r);            // r + rho
-    const f32x2 t1 = __builtin_elementwise_fma(-q, q, cc);
-    const f32x2 t2 = __builtin_elementwise_fma(dd, t1, -slack);           // |d|^2 (|co|^2 - (r + rho)^2) - slack
-    return __builtin_elementwise_fma(-h, h, t2);                          // < 0: the line comes near enough
+    const f32x2 grow = __builtin_elementwise_fma(r.w3, inv, r.w2);        // rho (2 r + rho) <= inv * grow
+    const f32x2 v = __builtin_elementwise_fma(grow, inv, m);
+    const f32x2 t2 = __builtin_elementwise_fma(r.dd, v, r.slack);
+    return __builtin_elementwise_fma(-h, h, -t2);                         // < 0: the line comes near enough
 }
 
 // triangle_group.py:302-399 for the triangles each lane noted, lowest index first
@@ -730,7 +749,6 @@ __device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_C
                                                          float t_min, float t_max, LaneQueue& q, Closest& best,
                                                          unsigned long long& evaluated) {
     const TriangleWalk w = {t_min, t_max, 0.0f, 0.0f, 0.0f};
-    const Ray2 r2 = both_halves(r);
     const int blocks = (count + 15) >> 4;
     BoundPair A = fetch_bound_pair(records), B;
     for (int block = 0; block < blocks; ++block) {
@@ -740,11 +758,11 @@ __device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_C
             WRT_SCALAR_LOADS_ARRIVED();
             B = fetch_bound_pair(records + 4);
             WRT_PIN();
-            mask = shift_in_signs(mask, sphere_reject2(r2, k, A));
+            mask = shift_in_signs(mask, sphere_reject2(k, A));
             WRT_SCALAR_LOADS_ARRIVED();
             A = fetch_bound_pair(records + 8);
             WRT_PIN();
-            mask = shift_in_signs(mask, sphere_reject2(r2, k, B));
+            mask = shift_in_signs(mask, sphere_reject2(k, B));
             records += 8;
         }
         // triangles past the group's end repeat its last one and are left out
@@ -806,8 +824,9 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
             if (pass_mask == 0ull) continue;
             pc.triangle += (unsigned long long)__popcll(pass_mask) * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
-            const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach, groups[g].c[0],
-                                                       groups[g].c[1], groups[g].c[2]);
+            const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach,
+                                                       groups[g].radius_max, groups[g].c[0], groups[g].c[1],
+                                                       groups[g].c[2]);
             if (S.prefilter && __ballot(!k.usable) == 0ull)
                 loop_triangles_rejecting(S, as_uniform(S.bounds) + groups[g].bound_base, g, first, count, k, r, t_min,
                                          t_max, q, best, pc.triangle_exact);
