@@ -86,7 +86,7 @@ def cpu_baseline(kind, sample, max_bounces, seed):
                                              "(reference itself, 1 of 8 cores)")
 
 
-def flop_counts(stats):
+def flop_counts(stats, hierarchy=False):
     """(algorithmic, executed) FP32 flops of the pairs in `stats`.
 
     algorithmic: what the reference evaluates for these pairs (triangle_group.py:289-395 45 flop,
@@ -94,20 +94,27 @@ def flop_counts(stats):
     issues: spheres meet a 15-flop bound of the discriminant, the full 19 only for candidates (not
     counted); triangles of large groups meet a 28-flop bounding-sphere test and the 45-flop evaluation
     only if they survive it; with the reject off (or in small groups) every pair costs 45 + 10 filter flops.
+    With hierarchy=True (--hierarchy) "algorithmic" still counts the pairs the reference would examine,
+    so the fraction built on it is a speed-up figure, not a utilisation.
     """
     tri, sph, cull = stats["triangle_pairs"], stats["sphere_pairs"], stats["cull_tests"]
     algorithmic = 45.0 * tri + 19.0 * sph + 14.0 * cull
     evaluated = stats["triangle_evaluations"]
     executed_tri = 28.0 * tri + 45.0 * evaluated if evaluated else 55.0 * tri
+    if hierarchy:
+        # only the leaf triangles a walk looked at (box tests are not counted): pairs of groups too small
+        # for a hierarchy are missing from this figure, it is a lower bound
+        executed_tri = 45.0 * evaluated
     return algorithmic, executed_tri + 15.0 * sph + 14.0 * cull
 
 
-def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True):
+def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True, hierarchy=False, spp=0):
     """One more workload on this GPU: Mrays/s, roofline fraction and the CPU figure, compactly."""
     import torch
     from weekend_raytracer import main as wr_main
-    kind, width, height, spp, bounces, cpu_sample, desc = WORKLOADS[name]
-    frame = wr_main.Frame(build_scene(kind, width / height), device=device)
+    kind, width, height, full_spp, bounces, cpu_sample, desc = WORKLOADS[name]
+    spp = spp or full_spp
+    frame = wr_main.Frame(build_scene(kind, width / height), device=device, hierarchy=hierarchy)
     ctx = frame.ctx
     ctx.set_triangle_reject(reject)
 
@@ -131,16 +138,19 @@ def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True):
     ctx.set_triangle_reject(True)
     ctx.close()
     segments = int(stats["rays_per_bounce"][:bounces].sum())
-    flops, executed = flop_counts(stats)
+    flops, executed = flop_counts(stats, hierarchy)
     value = segments / elapsed / 1e6
     out = {"workload": f"{name}: {desc}", "width": width, "height": height, "spp": spp, "max_bounces": bounces,
-           "triangle_reject": bool(reject),
+           "triangle_reject": bool(reject), "triangle_hierarchy": hierarchy,
            "value": round(value, 3), "unit": "Mrays/s", "seconds_per_frame": round(elapsed / steps, 6),
            "kernel_ms_avg": round(kernel_ms / max(1, launches), 4),
            "roofline_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
            "executed_frac": round(executed / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
            "triangle_pairs_fully_evaluated": round(stats["triangle_evaluations"] / max(1, stats["triangle_pairs"]), 5)
-           if reject else 1.0}
+           if reject or hierarchy else 1.0}
+    if hierarchy:
+        out["roofline_frac"] = None            # not the reference's work: no brute-force roofline figure
+        out["speedup_note"] = "box hierarchy: same closest hits bit for bit, fewer pairs examined than the reference does"
     if with_cpu:
         cpu = cpu_baseline(kind, cpu_sample, bounces, seed)
         out.update({"cpu_baseline": cpu, "gpu_over_cpu_port": round(value / cpu["value"], 1),
@@ -160,6 +170,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--full-evaluation", action="store_true",
                     help="no bounding-sphere reject: the reference's full evaluation for every ray-triangle pair")
+    ap.add_argument("--hierarchy", action="store_true",
+                    help="optional mode, not the reference's algorithm: large triangle groups are walked through a box "
+                         "hierarchy; same image bit for bit, and a figure to be read apart from the brute-force one")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
 
@@ -188,7 +201,7 @@ def main():
 
     kind, width, height, spp, bounces, cpu_sample, desc = WORKLOADS[args.workload]
     width, height, spp = args.width or width, args.height or height, args.spp or spp
-    frame = wr_main.Frame(build_scene(kind, width / height), device=local_rank)
+    frame = wr_main.Frame(build_scene(kind, width / height), device=local_rank, hierarchy=args.hierarchy)
     ctx = frame.ctx
     ctx.set_triangle_reject(not args.full_evaluation)
     s_begin = rank * spp                      # weak scaling: disjoint global sample ranges
@@ -227,7 +240,7 @@ def main():
     stats = ctx.stats()
 
     segments = int(stats["rays_per_bounce"][:bounces].sum())
-    flops, executed_flops = flop_counts(stats)
+    flops, executed_flops = flop_counts(stats, args.hierarchy)
     totals = torch.tensor([float(segments), elapsed], dtype=torch.float64,
                           device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
@@ -273,6 +286,7 @@ def main():
                 "parallelism": f"samples sharded over {world} GPU(s), RCCL all-reduce of the fp32 image"
                                if world > 1 else "single GPU",
                 "non_finite_pixels": bad_pixels,
+                "triangle_hierarchy": bool(args.hierarchy),
             },
             "roofline": {
                 "bound": "valu",
@@ -313,7 +327,14 @@ def main():
             # the mesh configuration the acceptance target is stated on, measured the same way (single GPU)
             out["also"] = {"bunny": side_measurement("bunny", args.seed, local_rank),
                            "bunny_full_evaluation": side_measurement("bunny", args.seed, local_rank, reject=False,
-                                                                     with_cpu=False)}
+                                                                     with_cpu=False),
+                           # optional mode, reported apart: not the reference's brute-force work
+                           "bunny_hierarchy": side_measurement("bunny", args.seed, local_rank, with_cpu=False,
+                                                               hierarchy=64),   # below the default threshold of 1024
+                           "cow_teapot_8spp": side_measurement("cow_teapot", args.seed, local_rank, steps=1,
+                                                               with_cpu=False, spp=8),
+                           "cow_teapot_8spp_hierarchy": side_measurement("cow_teapot", args.seed, local_rank, steps=1,
+                                                                         with_cpu=False, hierarchy=True, spp=8)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -91,7 +91,8 @@ typedef struct wrt_stats {
        (part of [2] and [3]) */
     uint64_t clock_ticks[8];
     /* (ray, triangle) pairs of the large groups that went through the full evaluation;
-       the others were rejected by the bounding-sphere test (see wrt_set_triangle_reject) */
+       the others were rejected by the bounding-sphere test (see wrt_set_triangle_reject)
+       or never looked at by a hierarchy walk (see wrt_set_hierarchy) */
     uint64_t triangle_evaluations;
 } wrt_stats;
 
@@ -168,6 +169,19 @@ int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_tot
    only the survivors get the full evaluation; results are the same bit for bit.
    on = 0: the full evaluation for every pair.  Takes effect with the next render. */
 int wrt_set_triangle_reject(wrt_ctx* ctx, int on);
+
+/* No counterpart in the reference either (its README lists a spatial structure as future
+   work).  min_triangles = 0 (default): every (ray, triangle) pair of a group that passes
+   the group's bounding-sphere cull (triangle_group.py:158-166) is examined, as the
+   reference does.  min_triangles = n > 0: groups of n or more triangles (at least 16, at
+   most 32768) are walked through a box hierarchy built by wrt_scene_commit; only the
+   triangles of the leaves a ray comes near get the evaluation of triangle_group.py:289-395.
+   The boxes are grown by a bound on that evaluation's float32 error, so the closest hit
+   (t, triangle, tie order) is the same bit for bit; the work done is not the reference's,
+   and throughput in this mode is to be reported apart from the brute-force figure.  On one
+   MI355X the walk overtakes the brute-force loops at about 1000 triangles per group.
+   Takes effect with the next render or intersect. */
+int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles);
 
 int wrt_stats_reset(wrt_ctx* ctx, void* stream);
 /* synchronises `stream`, then copies the statistics out */

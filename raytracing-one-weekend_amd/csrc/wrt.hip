@@ -75,6 +75,10 @@ static constexpr int CHEAP_GROUP_MAX = 8;      // groups up to this size are eva
 static constexpr int TRIP_COST = WRT_TRIP_COST;          // wave-instructions of one shade/refill/advance trip (estimate)
 static constexpr int TRIANGLE_COST = WRT_TRIANGLE_COST;  // wave-instructions per primitive of the uniform loops (estimate)
 static constexpr int SPHERE_COST = WRT_SPHERE_COST;
+#ifndef WRT_TREE_VISIT_COST
+#define WRT_TREE_VISIT_COST 270
+#endif
+static constexpr int TREE_VISIT_COST = WRT_TREE_VISIT_COST;   // wave-instructions per node or leaf a walk looks at (estimate)
 
 // Waves per SIMD the kernel is compiled for: 6 (80 VGPRs) measures 1-1.5 % faster than 8
 // (64 VGPRs, more of the shading code in scratch) and 4-7 % faster than 4; the extra
@@ -112,6 +116,9 @@ __device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
 #pragma clang diagnostic pop
 }
 
+// WALK: the instance launched when hierarchies are switched on; the other one carries none of the
+// walk's code (compiled into one kernel it costs the sphere loops 2 % through register allocation).
+template <bool WALK>
 __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
@@ -327,9 +334,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             int run_g = -1, run_n = 0, run_slot = -1;
             const WRT_CONST int* slots = as_uniform(S.slot_group);
             const int n_slots = S.n_slots;
+            const int walk_from = S.hierarchy;
             for (int k = 0; k < n_slots; ++k) {
                 const int n = (int)__popcll(__ballot(((pending >> k) & 1u) != 0u));
-                long long need = 64 - (64ll * TRIP_COST) / slots[32 + k];
+                const bool walked = WALK && walk_from != 0 && slots[96 + k] >= walk_from;
+                long long need = 64 - (64ll * TRIP_COST) / slots[(walked ? 64 : 32) + k];
                 need = need < 8 ? 8 : need;
                 if (n > run_n && (n >= need || !more_cheap)) { run_n = n; run_slot = k; }
             }
@@ -365,7 +374,18 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach,
                                                            ugroups[run_g].radius_max, ugroups[run_g].c[0],
                                                            ugroups[run_g].c[1], ugroups[run_g].c[2]);
-                if (S.prefilter && __ballot(!k.usable) == 0ull)
+                bool walked = false;
+                if (WALK && S.hierarchy != 0 && ugroups[run_g].tree_base >= 0 && count >= S.hierarchy) {
+                    const TreeRay w = tree_ray_setup(ray, mine, ugroups[run_g].reach2, ugroups[run_g].c[0],
+                                                     ugroups[run_g].c[1], ugroups[run_g].c[2]);
+                    if (__ballot(!w.usable) == 0ull) {
+                        walk_tree(S.tree + ugroups[run_g].tree_base, run_g, first, w, ray, mine, t_min, t_max, queue,
+                                  best, pc.triangle_exact);
+                        walked = true;
+                    }
+                }
+                if (walked) {
+                } else if (S.prefilter && __ballot(!k.usable) == 0ull)
                     loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count,
                                              k, ray, t_min, t_max, queue, best, pc.triangle_exact);
                 else
@@ -552,7 +572,9 @@ struct wrt_ctx {
     std::vector<f32x4> h_pairs;
     std::vector<f32x4> h_bounds;
     std::vector<int> h_slot_group, h_slot_table;
+    std::vector<f32x4> h_tree;
     int triangle_reject = 1;
+    int hierarchy = 0;
     MaterialRec h_materials[WRT_MAX_MATERIALS];
     float* d_textures[WRT_MAX_TEXTURES] = {nullptr};
     TextureRec h_textures[WRT_MAX_TEXTURES];
@@ -604,6 +626,7 @@ static void reset_scene(wrt_ctx* ctx) {
     std::memset(ctx->h_materials, 0, sizeof(ctx->h_materials));
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
     ctx->scene.prefilter = ctx->triangle_reject;
+    ctx->scene.hierarchy = ctx->hierarchy;
     std::memset(&ctx->h_cam, 0, sizeof(ctx->h_cam));
     ctx->scene.horizon[0] = ctx->scene.horizon[1] = ctx->scene.horizon[2] = 1.0f;
     ctx->scene.zenith[0] = 0.5f; ctx->scene.zenith[1] = 0.7f; ctx->scene.zenith[2] = 1.0f;
@@ -896,6 +919,178 @@ static void build_bounds(wrt_ctx* ctx) {
     for (int i = 0; i < 8; ++i) ctx->h_bounds.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
 }
 
+// Box hierarchy of each triangle group of TREE_MIN_TRIANGLES or more (walk_tree): split planes by the
+// surface-area heuristic among those that keep the height within the walk's stack (else halves by
+// count at the median centroid along the widest axis);
+// boxes relative to the group's bounds centre, rounded outwards; kappa as walk_tree's comment derives it.
+static constexpr int TREE_MIN_TRIANGLES = 16;
+#ifndef WRT_TREE_LEAF
+#define WRT_TREE_LEAF 4
+#endif
+static constexpr int TREE_LEAF = WRT_TREE_LEAF;                // triangles per leaf where the height allows it
+static constexpr int TREE_MAX_TRIANGLES = 8 << QUEUE_SLOTS;     // 8 per leaf, height QUEUE_SLOTS
+struct TreeTriangle { double lo[3], hi[3], mid[3]; float kappa; int prim; };
+struct TreeBox { float lo[3], hi[3], kappa; };
+struct TreeNode { TreeBox box[2]; int child[2]; };
+
+static int build_tree_range(std::vector<TreeTriangle>& t, int lo, int hi, int leaf_max, int height,
+                            std::vector<TreeNode>& nodes, TreeBox& box) {
+    double blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    double mlo[3] = {INFINITY, INFINITY, INFINITY}, mhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    box.kappa = 0.0f;
+    for (int i = lo; i < hi; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            blo[a] = std::min(blo[a], t[(size_t)i].lo[a]); bhi[a] = std::max(bhi[a], t[(size_t)i].hi[a]);
+            mlo[a] = std::min(mlo[a], t[(size_t)i].mid[a]); mhi[a] = std::max(mhi[a], t[(size_t)i].mid[a]);
+        }
+        box.kappa = std::max(box.kappa, t[(size_t)i].kappa);
+    }
+    for (int a = 0; a < 3; ++a) {
+        box.lo[a] = std::nextafter((float)blo[a], -INFINITY);
+        box.hi[a] = std::nextafter((float)bhi[a], INFINITY);
+    }
+    const int n = hi - lo;
+    if (n <= leaf_max) return -1 - (lo * 8 + (n - 1));          // slot of its first triangle, fixed up by the caller
+    // a child may hold at most leaf_max << (height - 1) triangles: the walk's stack has `height` entries
+    const long long child_cap = (long long)leaf_max << (height - 1);
+    const int k_min = (int)std::max<long long>(1, n - child_cap), k_max = (int)std::min<long long>(n - 1, child_cap);
+    // surface-area heuristic over 16 centroid bins per axis; each triangle box grown by its own kappa share
+    // is not modelled: plain areas
+    enum { BINS = 16 };
+    int best_axis = -1, best_bin = 0;
+    double best_cost = INFINITY;
+    for (int axis = 0; axis < 3; ++axis) {
+        const double span = mhi[axis] - mlo[axis];
+        if (!(span > 0.0)) continue;
+        struct Bin { double lo[3], hi[3]; int n; } bins[BINS];
+        for (Bin& b : bins) { for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } b.n = 0; }
+        for (int i = lo; i < hi; ++i) {
+            const TreeTriangle& k = t[(size_t)i];
+            int b = (int)((k.mid[axis] - mlo[axis]) / span * BINS);
+            b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+            for (int a = 0; a < 3; ++a) { bins[b].lo[a] = std::min(bins[b].lo[a], k.lo[a]); bins[b].hi[a] = std::max(bins[b].hi[a], k.hi[a]); }
+            ++bins[b].n;
+        }
+        auto area = [](const double* l, const double* h) {
+            const double x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2];
+            return x * y + y * z + z * x;
+        };
+        double right_area[BINS];
+        int right_n[BINS];
+        {
+            double l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+            int cnt = 0;
+            for (int b = BINS - 1; b > 0; --b) {
+                for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], bins[b].lo[a]); h[a] = std::max(h[a], bins[b].hi[a]); }
+                cnt += bins[b].n;
+                right_area[b] = cnt ? area(l, h) : 0.0;
+                right_n[b] = cnt;
+            }
+        }
+        double l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int cnt = 0;
+        for (int b = 0; b + 1 < BINS; ++b) {                  // split after bin b
+            for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], bins[b].lo[a]); h[a] = std::max(h[a], bins[b].hi[a]); }
+            cnt += bins[b].n;
+            if (cnt < k_min || cnt > k_max || right_n[b + 1] == 0 || cnt == 0) continue;
+            const double cost = area(l, h) * cnt + right_area[b + 1] * right_n[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+    }
+    int mid;
+    if (best_axis >= 0) {
+        const int axis = best_axis;
+        const double span = mhi[axis] - mlo[axis], origin = mlo[axis];
+        const int bin = best_bin;
+        auto left = [=](const TreeTriangle& k) {
+            int b = (int)((k.mid[axis] - origin) / span * BINS);
+            b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+            return b <= bin;
+        };
+        mid = (int)(std::stable_partition(t.begin() + lo, t.begin() + hi, left) - t.begin());
+    } else {
+        // no admissible plane: halves by count at the median centroid along the widest axis
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (mhi[a] - mlo[a] > mhi[axis] - mlo[axis]) axis = a;
+        mid = lo + (n + 1) / 2;
+        std::nth_element(t.begin() + lo, t.begin() + mid, t.begin() + hi, [axis](const TreeTriangle& x, const TreeTriangle& y) {
+            return x.mid[axis] < y.mid[axis] || (x.mid[axis] == y.mid[axis] && x.prim < y.prim);
+        });
+    }
+    const size_t at = nodes.size();
+    nodes.emplace_back();
+    TreeBox b0, b1;
+    const int c0 = build_tree_range(t, lo, mid, leaf_max, height - 1, nodes, b0);
+    const int c1 = build_tree_range(t, mid, hi, leaf_max, height - 1, nodes, b1);
+    nodes[at].box[0] = b0; nodes[at].box[1] = b1; nodes[at].child[0] = c0; nodes[at].child[1] = c1;
+    return (int)at * 4;
+}
+
+static void build_trees(wrt_ctx* ctx) {
+    ctx->h_tree.clear();
+    auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
+    for (GroupRec& g : ctx->h_groups) {
+        g.tree_base = -1; g.reach2 = 0.0f;
+        if (g.type != GROUP_TRIANGLES || g.count < TREE_MIN_TRIANGLES || g.count > TREE_MAX_TRIANGLES) continue;
+        std::vector<TreeTriangle> t((size_t)g.count);
+        double reach2 = 0.0;
+        bool finite = true;
+        for (int j = 0; j < g.count; ++j) {
+            const size_t i = (size_t)g.first + j;
+            const f32x4 r0 = ctx->h_tri[2 * i], r1 = ctx->h_tri[2 * i + 1];
+            const double P[3] = {r0.x, r0.y, r0.z}, A[3] = {r0.w, r1.x, r1.y}, B[3] = {r1.z, r1.w, ctx->h_tri_bz[i]};
+            TreeTriangle& k = t[(size_t)j];
+            double d2[3] = {0.0, 0.0, 0.0};
+            for (int a = 0; a < 3; ++a) {
+                // the corners the evaluation works with, P0, P0 + A, P0 + B, relative to the centre
+                const double v[3] = {P[a] - (double)g.c[a], P[a] + A[a] - (double)g.c[a], P[a] + B[a] - (double)g.c[a]};
+                k.lo[a] = std::min(v[0], std::min(v[1], v[2]));
+                k.hi[a] = std::max(v[0], std::max(v[1], v[2]));
+                k.mid[a] = (v[0] + v[1] + v[2]) / 3.0;
+                for (int c = 0; c < 3; ++c) d2[c] += v[c] * v[c];
+                finite = finite && std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]);
+            }
+            reach2 = std::max(reach2, std::sqrt(std::max(d2[0], std::max(d2[1], d2[2]))));
+            const double la = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]),
+                         lb = std::sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]);
+            k.kappa = std::nextafter((float)(0.17 * la * lb), INFINITY);
+            k.prim = j;
+            finite = finite && std::isfinite(k.kappa);
+        }
+        if (!finite || !(reach2 < 1e30)) continue;
+        const int leaf_max = g.count <= (TREE_LEAF << QUEUE_SLOTS) ? TREE_LEAF : 8;
+        std::vector<TreeNode> nodes;
+        TreeBox whole;
+        // count >= TREE_MIN_TRIANGLES: the root is a node
+        build_tree_range(t, 0, g.count, leaf_max, QUEUE_SLOTS, nodes, whole);
+        g.tree_base = (int)ctx->h_tree.size();
+        g.reach2 = std::nextafter((float)reach2, INFINITY);
+        const int leaves_at = (int)nodes.size() * 4;
+        for (const TreeNode& n : nodes) {
+            int child[2];
+            for (int c = 0; c < 2; ++c) {
+                child[c] = n.child[c];
+                if (child[c] < 0) {
+                    const int code = -1 - child[c];
+                    child[c] = -1 - ((leaves_at + 3 * (code >> 3)) * 8 + (code & 7));
+                }
+            }
+            const TreeBox &a = n.box[0], &b = n.box[1];
+            ctx->h_tree.push_back(f32x4{a.lo[0], a.lo[1], a.lo[2], a.hi[0]});
+            ctx->h_tree.push_back(f32x4{a.hi[1], a.hi[2], b.lo[0], b.lo[1]});
+            ctx->h_tree.push_back(f32x4{b.lo[2], b.hi[0], b.hi[1], b.hi[2]});
+            ctx->h_tree.push_back(f32x4{a.kappa, b.kappa, as_float(child[0]), as_float(child[1])});
+        }
+        for (const TreeTriangle& k : t) {
+            const size_t i = (size_t)g.first + k.prim;
+            ctx->h_tree.push_back(ctx->h_tri[2 * i]);
+            ctx->h_tree.push_back(ctx->h_tri[2 * i + 1]);
+            ctx->h_tree.push_back(f32x4{ctx->h_tri_bz[i], as_float(k.prim), 0.0f, 0.0f});
+        }
+    }
+    ctx->h_tree.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+}
+
 int wrt_scene_commit(wrt_ctx* ctx) {
     if (int r = bind(ctx)) return r;
     for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
@@ -954,6 +1149,7 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     // the loops fetch one step past a group's end: keep that read inside the array
     for (int i = 0; i < 8; ++i) ctx->h_pairs.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
     build_bounds(ctx);
+    build_trees(ctx);
     // slots of the large groups (see k_render, phase d)
     ctx->h_slot_group.clear();
     for (size_t i = 0; i < ctx->h_groups.size(); ++i) {
@@ -964,12 +1160,16 @@ int wrt_scene_commit(wrt_ctx* ctx) {
             ctx->h_slot_group.push_back((int)i);
         }
     }
-    {   // [0, 32): group index of each slot, [32, 64): estimated wave-instructions of its loop
-        std::vector<int> table(64, 1);
+    {   // [0, 32): group index of each slot, [32, 64): estimated wave-instructions of its loop,
+        // [64, 96): the same when its hierarchy is walked, [96, 128): its count if it has a hierarchy, else -1
+        std::vector<int> table(128, 1);
         for (size_t k = 0; k < ctx->h_slot_group.size(); ++k) {
             const GroupRec& g = ctx->h_groups[ctx->h_slot_group[k]];
             table[k] = ctx->h_slot_group[k];
             table[32 + k] = g.count * (g.type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
+            table[64 + k] = g.tree_base >= 0 ? (int)(TREE_VISIT_COST * (2.0 * std::log2((double)g.count) + 10.0))
+                                             : table[32 + k];
+            table[96 + k] = g.tree_base >= 0 ? g.count : -1;
         }
         ctx->h_slot_table = table;
     }
@@ -981,8 +1181,10 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                  b_grp = up(ctx->h_groups.size() * sizeof(GroupRec) + 16), b_mat = up(sizeof(ctx->h_materials)),
                  b_tex = up(sizeof(ctx->h_textures)), b_cam = up(sizeof(ctx->h_cam)),
                  b_pairs = up(ctx->h_pairs.size() * sizeof(f32x4) + 16),
-                 b_bounds = up(ctx->h_bounds.size() * sizeof(f32x4) + 16), b_slots = up(64 * sizeof(int));
-    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs + b_bounds + b_slots;
+                 b_bounds = up(ctx->h_bounds.size() * sizeof(f32x4) + 16), b_slots = up(128 * sizeof(int)),
+                 b_tree = up(ctx->h_tree.size() * sizeof(f32x4) + 16);
+    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs +
+                         b_bounds + b_slots + b_tree;
     if (total > ctx->blob_bytes) {
         if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
@@ -1010,6 +1212,7 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     S.pairs = (const f32x4*)put(ctx->h_pairs.data(), ctx->h_pairs.size() * sizeof(f32x4), b_pairs);
     S.bounds = (const f32x4*)put(ctx->h_bounds.data(), ctx->h_bounds.size() * sizeof(f32x4), b_bounds);
     S.slot_group = (const int*)put(ctx->h_slot_table.data(), ctx->h_slot_table.size() * sizeof(int), b_slots);
+    S.tree = (const f32x4*)put(ctx->h_tree.data(), ctx->h_tree.size() * sizeof(f32x4), b_tree);
     S.n_slots = (int)ctx->h_slot_group.size();
     S.n_groups = (int)ctx->h_groups.size();
     HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
@@ -1062,7 +1265,8 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
         A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
         // persistent grid: as many workgroups as stay resident
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render, RENDER_BLOCK, 0) != hipSuccess ||
+        void (*const kernel)(const RenderLaunch) = ctx->hierarchy != 0 ? k_render<true> : k_render<false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RENDER_BLOCK, 0) != hipSuccess ||
             per_cu < 1)
             per_cu = 1;
         long long waves_wanted = A.n_batches;
@@ -1075,7 +1279,7 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
             HIP_TRY(ctx, hipEventCreate(&ev1));
             HIP_TRY(ctx, hipEventRecord(ev0, st));
         }
-        hipLaunchKernelGGL(k_render, dim3(blocks), dim3(RENDER_BLOCK), 0, st, RenderLaunch{ctx->scene, A});
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RENDER_BLOCK), 0, st, RenderLaunch{ctx->scene, A});
         HIP_TRY(ctx, hipGetLastError());
         if (ctx->profiling) {
             HIP_TRY(ctx, hipEventRecord(ev1, st));
@@ -1126,6 +1330,14 @@ int wrt_set_triangle_reject(wrt_ctx* ctx, int on) {
     if (int r = bind(ctx)) return r;
     ctx->triangle_reject = on ? 1 : 0;
     ctx->scene.prefilter = ctx->triangle_reject;
+    return WRT_OK;
+}
+
+int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles) {
+    if (int r = bind(ctx)) return r;
+    if (min_triangles < 0) return fail(ctx, WRT_E_ARG, "wrt_set_hierarchy: negative triangle count");
+    ctx->hierarchy = min_triangles;
+    ctx->scene.hierarchy = ctx->hierarchy;
     return WRT_OK;
 }
 

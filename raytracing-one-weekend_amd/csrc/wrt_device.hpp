@@ -40,7 +40,8 @@ struct GroupRec {            // 112 bytes, uniform
     float reach;             // triangles: largest |coordinate - c| of any corner or bounding-sphere centre
     int slot;                // large groups: bit of the render kernel's pending mask, -1 = none
     float radius_max;        // triangles: largest radius of the bounding records
-    int pad[2];
+    int tree_base;           // triangles: first f32x4 of the group's box hierarchy, -1 = none
+    float reach2;            // triangles with a hierarchy: largest distance of any corner from c
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -84,7 +85,10 @@ struct SceneRec {
     const f32x4* pairs;           // sphere and triangle groups again, two primitives per record (group loops)
     const f32x4* bounds;          // per triangle: bounding sphere and B x A, two triangles per record
     int prefilter;                // 1: triangle loops reject by bounding sphere first
-    const int* slot_group;        // [0, 32): group index of each slot, [32, 64): cost estimate of its loop
+    const f32x4* tree;            // box hierarchies of the large triangle groups: nodes, then leaf triangles
+    int hierarchy;                // n > 0: triangle groups of n or more triangles that have a hierarchy are walked through it
+    const int* slot_group;        // [0, 32): group index of each slot, [32, 64): cost estimate of its loop,
+                                  // [64, 96): cost estimate with the hierarchy, [96, 128): count if it has one, else -1
     int n_slots;
     float horizon[3], zenith[3];
     int n_groups;
@@ -775,6 +779,154 @@ __device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_C
     drain_triangle_blocks(S, q, g, first, r, w, best, evaluated);
 }
 
+// ---- optional: a lane walks a triangle group's box hierarchy on its own ------
+// Not the reference's algorithm (it looks at every pair): an optional mode that evaluates
+// triangle_terms / triangle_exact only for the triangles of the leaves a ray's line comes near,
+// with the same closest hit.  What makes it the same hit:
+//
+// With exact tvec = o - P0 and Cramer's identity det tvec = un A + vn B - tn d for the exact
+// numerators, the float32 evaluation (round to nearest, u = 2^-24, no fused operations, the
+// association of triangle_terms) returns det_c, un_c, vn_c, tn_c with
+//     |det_c - det| <= 5.83u |d||A||B|,   |un_c - un|, |vn_c - vn|, |tn_c - tn| <= 6.83u |tvec| x
+//     (|d||B|, |d||A|, |A||B|)
+// (a 3-term dot product errs by at most 3u |x||y|, a cross product by 2.83u |a||b| in norm,
+// o - P0 by u |tvec|).  For a reported hit (|det_c| >= 1e-5, 0 <= u_c, v_c, u_c + v_c <= 1 + u,
+// two more roundings each in u_c, v_c, t_c) the residual of the reported point,
+//     R = (o + t_c d) - (P0 + u_c A + v_c B),
+// obeys |R| <= 26.4u |tvec||d||A||B| / 1e-5 + 2.1u (|tvec| + 2|A| + 2|B| + |R|)
+//          <= 0.158 |A||B| |d| T2 + 2e-6 T2        with T2 >= |o - P0|, |A|, |B| <= 2 T2.
+// So o + t_c d lies in any box around the triangle's corners that is grown by that much, and
+// t_c inside the box's parameter interval.  A node stores kappa = 0.17 max |A||B| over its
+// triangles; the ray brings s >= |d| T2 and a = 3e-6 T2 + 1e-30 (which also covers the
+// rounding of o - c, of the box corners' subtractions, and of kappa s).  The interval's ends
+// carry at most 4 roundings (v_rcp_f32: 1 ulp), allowed for by the factors 1 -+ 1e-6.
+// A node is left out only when its interval misses [t_min, min(best t, t_max)]; equal t still
+// gets in, and the tie rule below is the brute-force loops' rule (lowest index inside the
+// group, earlier group across groups) in a form that does not depend on the order of evaluation.
+struct TreeRay {
+    float ox, oy, oz;      // o - c
+    float ix, iy, iz;      // 1 / d (v_rcp_f32)
+    float mx, my, mz;      // -(o - c) / d
+    float s, a;            // box growth = kappa * s + a
+    bool usable;           // the bounds above hold (finite, no overflow) for this lane
+};
+__device__ __forceinline__ TreeRay tree_ray_setup(const Ray& r, bool active, float reach2, float gx, float gy,
+                                                  float gz) {
+    TreeRay k;
+    k.ox = r.ox - gx; k.oy = r.oy - gy; k.oz = r.oz - gz;
+    // A direction component below 1e-18 of the largest is replaced by that (same sign): the point at
+    // parameter t moves by less than 1e-17 T2 for every t that can be a hit, and 1 / d stays finite.
+    const float d_max = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz)), d_floor = 1.0e-18f * d_max;
+    const float dx = fabsf(r.dx) < d_floor ? copysignf(d_floor, r.dx) : r.dx;
+    const float dy = fabsf(r.dy) < d_floor ? copysignf(d_floor, r.dy) : r.dy;
+    const float dz = fabsf(r.dz) < d_floor ? copysignf(d_floor, r.dz) : r.dz;
+    k.ix = __builtin_amdgcn_rcpf(dx); k.iy = __builtin_amdgcn_rcpf(dy); k.iz = __builtin_amdgcn_rcpf(dz);
+    k.mx = -k.ox * k.ix; k.my = -k.oy * k.iy; k.mz = -k.oz * k.iz;
+    const float oo = (k.ox * k.ox + k.oy * k.oy) + k.oz * k.oz, dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    const float T2 = (sqrtf(oo) + reach2) * 1.000001f;
+    k.s = 1.000001f * sqrtf(dd) * T2;
+    k.a = 3.0e-6f * T2 + 1.0e-30f;
+    // written so that a NaN or infinite ray is not usable; within these limits no product of the box
+    // test is infinity times zero or infinity minus infinity
+    k.usable = !active || (T2 <= 1.0e9f && d_max >= 1.0e-9f && d_max <= 1.0e9f);
+    return k;
+}
+
+// parameter interval of the ray inside the grown box; true when it meets [t_min, upper]
+__device__ __forceinline__ bool tree_box(const TreeRay& k, float lox, float loy, float loz, float hix, float hiy,
+                                         float hiz, float kappa, float t_min, float upper, float& t_near) {
+    const float grow = __builtin_fmaf(kappa, k.s, k.a);
+    // (plane - o) / d as plane * (1/d) - o * (1/d): the rounding of the second product moves the
+    // plane by at most u |o|, inside `a`
+    const float x1 = __builtin_fmaf(lox - grow, k.ix, k.mx), x2 = __builtin_fmaf(hix + grow, k.ix, k.mx);
+    const float y1 = __builtin_fmaf(loy - grow, k.iy, k.my), y2 = __builtin_fmaf(hiy + grow, k.iy, k.my);
+    const float z1 = __builtin_fmaf(loz - grow, k.iz, k.mz), z2 = __builtin_fmaf(hiz + grow, k.iz, k.mz);
+    t_near = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+    const float t_far = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+    return fmaxf(t_near * 0.999999f, t_min) <= fminf(t_far * 1.000001f, upper);
+}
+
+// A node is 4 x f32x4: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (kappa0, kappa1, child0, child1),
+// boxes relative to the group's bounds centre.  child >= 0: f32x4 offset of an inner node from the
+// group's root; child < 0: -1 - (offset * 8 + n - 1), n <= 8 leaf triangles of 3 x f32x4 each,
+// (P0, A.x) (A.yz, B.xy) (B.z, index inside the group, -, -), the numbers of S.tri / S.tri_bz.
+// The lane's stack lives in its queue slots (QUEUE_SLOTS entries: the builder keeps trees that low).
+enum { TREE_DONE = -2147483647 - 1 };
+#ifndef WRT_WALK_NUM
+#define WRT_WALK_NUM 1
+#define WRT_WALK_DEN 2
+#endif
+#ifndef WRT_WALK_BOTH
+#define WRT_WALK_BOTH 0
+#endif
+__device__ __forceinline__ void walk_tree(const f32x4* __restrict__ tree, int g, int first, const TreeRay& k,
+                                          const Ray& r, bool active, float t_min, float t_max, LaneQueue& q,
+                                          Closest& best, unsigned long long& evaluated) {
+    int node = active ? 0 : TREE_DONE;
+    int sp = 0;
+    unsigned looked_at = 0u;
+    for (;;) {
+        const unsigned long long inner = __ballot(node >= 0);
+        const unsigned long long leaf = __ballot(node < 0 && node != TREE_DONE);
+        if ((inner | leaf) == 0ull) break;
+        // lanes at a leaf wait while most of the others still go down
+        const bool go_down = inner != 0ull && WRT_WALK_DEN * __popcll(leaf) < WRT_WALK_NUM * __popcll(inner | leaf);
+        if (WRT_WALK_BOTH || go_down) {
+            if (node >= 0) {
+                const f32x4* n = tree + node;
+                const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                const float upper = fminf(best.t, t_max);
+                float near0, near1;
+                const bool in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
+                const bool in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
+                int c0 = (int)__float_as_uint(q3.z), c1 = (int)__float_as_uint(q3.w);
+                if (in0 && in1) {
+                    if (near1 < near0) { const int c = c0; c0 = c1; c1 = c; }
+                    q.slot[sp * 64] = (unsigned)c1;
+                    ++sp;
+                    node = c0;
+                } else if (in0) {
+                    node = c0;
+                } else if (in1) {
+                    node = c1;
+                } else if (sp > 0) {
+                    --sp;
+                    node = (int)q.slot[sp * 64];
+                } else {
+                    node = TREE_DONE;
+                }
+            }
+        }
+        if (WRT_WALK_BOTH || !go_down) {
+            if (node < 0 && node != TREE_DONE) {
+                const int code = -1 - node;
+                const int n = (code & 7) + 1;
+                const f32x4* rec = tree + (code >> 3);
+                looked_at += (unsigned)n;
+                for (int j = 0; j < n; ++j, rec += 3) {
+                    const f32x4 a = rec[0], b = rec[1], c = rec[2];
+                    const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x);
+                    float t;
+                    if (triangle_exact(terms, t_min, t_max, t)) {
+                        const int prim = first + (int)__float_as_uint(c.y);
+                        if (t < best.t || (t == best.t && (g < best.group || (g == best.group && prim < best.prim)))) {
+                            best.t = t; best.group = g; best.prim = prim;
+                        }
+                    }
+                }
+                if (sp > 0) {
+                    --sp;
+                    node = (int)q.slot[sp * 64];
+                } else {
+                    node = TREE_DONE;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) looked_at += (unsigned)__shfl_xor((int)looked_at, off);
+    evaluated += looked_at;
+}
+
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
 __device__ __forceinline__ void lane_spheres(SceneArg S, int g, int first, int count, const Ray& r,
                                              float t_min, float sentinel, Closest& best) {
@@ -827,7 +979,18 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
             const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach,
                                                        groups[g].radius_max, groups[g].c[0], groups[g].c[1],
                                                        groups[g].c[2]);
-            if (S.prefilter && __ballot(!k.usable) == 0ull)
+            bool walked = false;
+            if (S.hierarchy != 0 && groups[g].tree_base >= 0 && count >= S.hierarchy) {
+                const TreeRay w = tree_ray_setup(r, pass, groups[g].reach2, groups[g].c[0], groups[g].c[1],
+                                                 groups[g].c[2]);
+                if (__ballot(!w.usable) == 0ull) {
+                    walk_tree(S.tree + groups[g].tree_base, g, first, w, r, pass, t_min, t_max, q, best,
+                              pc.triangle_exact);
+                    walked = true;
+                }
+            }
+            if (walked) {
+            } else if (S.prefilter && __ballot(!k.usable) == 0ull)
                 loop_triangles_rejecting(S, as_uniform(S.bounds) + groups[g].bound_base, g, first, count, k, r, t_min,
                                          t_max, q, best, pc.triangle_exact);
             else

@@ -70,12 +70,16 @@ SIGNATURES = {
     "wrt_profile_enable": [_vp, _i],
     "wrt_profile_read": [_vp, ctypes.POINTER(ctypes.c_double), _ip],
     "wrt_set_triangle_reject": [_vp, _i],
+    "wrt_set_hierarchy": [_vp, _i],
     "wrt_stats_reset": [_vp, _vp],
     "wrt_stats_read": [_vp, ctypes.POINTER(WrtStats), _vp],
     "wrt_generate_rays": [_vp, _i, _i, _i, _i, _u64, _vp, _vp, _vp],
     "wrt_intersect": [_vp, _i, _vp, _vp, _i64, _f, _f] + [_vp] * 9 + [_vp],
     "wrt_scatter": [_vp, _i] + [_vp] * 8 + [_i, _u64, _i64, _vp, _vp, _vp, _vp],
 }
+
+# group size from which the hierarchy walk is faster than the brute-force loops (measured on one MI355X)
+HIERARCHY_MIN_TRIANGLES = 1024
 
 _lib = None
 
@@ -320,6 +324,13 @@ class Context:
     def set_triangle_reject(self, on):
         """Bounding-sphere test in front of the triangle evaluation (default on); same results either way."""
         self.check(self.lib.wrt_set_triangle_reject(self.handle, 1 if on else 0), "wrt_set_triangle_reject")
+
+    def set_hierarchy(self, on):
+        """Walk large triangle groups through a box hierarchy (default off: every pair is examined, as the
+        reference does); same closest hits either way, different amount of work.  True: groups of
+        HIERARCHY_MIN_TRIANGLES or more; an int: groups of that many triangles or more."""
+        n = HIERARCHY_MIN_TRIANGLES if on is True else int(on or 0)
+        self.check(self.lib.wrt_set_hierarchy(self.handle, n), "wrt_set_hierarchy")
 
     def stats_reset(self):
         self.check(self.lib.wrt_stats_reset(self.handle, self.stream()), "wrt_stats_reset")

@@ -22,6 +22,10 @@ T_MIN = 0.001
 T_MAX = 1000.0
 # key of the random streams (the reference uses unseeded generators, main.py:23)
 SEED = 0
+# Optional, not in the reference: walk large triangle groups through a box hierarchy instead of
+# examining every (ray, triangle) pair.  Same image bit for bit, less work.
+HIERARCHY = False
+
 # scene rendered by render(); the reference selects it by editing main.py:79-91
 SCENE = scenes.ray_group_triangle_group_bunny_scene
 
@@ -29,9 +33,10 @@ SCENE = scenes.ray_group_triangle_group_bunny_scene
 class Frame():
     """A scene resident on one GPU, ready to be rendered repeatedly."""
 
-    def __init__(self, scene, device=None):
+    def __init__(self, scene, device=None, hierarchy=None):
         camera, groups, material_map = scene
         self.ctx = _native.Context(device)
+        self.ctx.set_hierarchy(HIERARCHY if hierarchy is None else hierarchy)
         self.ctx.upload(_flatten.flatten(camera, groups, material_map, HORIZON_COLOUR, SKY_COLOUR))
 
     def accumulate(self, width, height, s_begin, s_end, max_bounces, seed, accum=None, paths=None):

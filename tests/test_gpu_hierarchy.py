@@ -1,0 +1,134 @@
+"""
+Walking a triangle group through its box hierarchy (wrt_set_hierarchy) must find the
+closest hit the brute-force loops find, bit for bit, ties included: whole frames
+both ways are compared path by path, single rays (axis-parallel ones, rays that start
+on a surface, rays along edges and through corners among them) hit by hit, on the
+shipped meshes, on scaled and shifted meshes against the oracle, and at the benchmark's
+full size.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import numpy_path
+from tests.test_gpu_reject import Flat, mesh_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def scene_objects(fn, aspect):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(aspect)
+
+
+def both_ways(objs, w, h, s, b, seed):
+    import torch
+    from weekend_raytracer import main
+    out = []
+    for hierarchy in (True, False):
+        frame = main.Frame(objs, hierarchy=16 if hierarchy else 0)
+        frame.ctx.stats_reset()
+        paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
+        frame.accumulate(w, h, 0, s, b, seed, paths=paths)
+        out.append((paths.cpu().numpy(), frame.ctx.stats()))
+        frame.ctx.close()
+    return out
+
+
+@pytest.mark.parametrize("name,size", [
+    ("ray_group_triangle_group_bunny_scene", (320, 180, 6, 10)),
+    ("cloth_bunny_scene", (256, 144, 4, 8)),
+    ("cow_teapot_field_scene", (320, 180, 4, 8)),
+    ("bunny_diffuse_scene", (1920, 1080, 30, 10)),        # the benchmark's mesh configuration, full size
+])
+def test_hierarchy_changes_nothing(name, size):
+    from weekend_raytracer import scenes
+    w, h, s, b = size
+    objs = scene_objects(getattr(scenes, name), w / h)
+    (p_on, st_on), (p_off, st_off) = both_ways(objs, w, h, s, b, seed=2025)
+    assert np.array_equal(p_on.view(np.uint32), p_off.view(np.uint32))
+    assert np.array_equal(st_on["rays_per_bounce"], st_off["rays_per_bounce"])
+    # the pairs the reference would have examined are counted the same; far fewer are evaluated
+    assert st_on["triangle_pairs"] == st_off["triangle_pairs"] > 0
+    assert 0 < st_on["triangle_evaluations"] < 0.1 * st_on["triangle_pairs"]
+
+
+@pytest.mark.parametrize("scale,offset", [
+    (1.0, (0.0, 0.0, 0.0)),
+    (0.01, (0.0, 0.0, 0.0)),
+    (1.0, (300.0, -200.0, 150.0)),
+    (0.06, (8000.0, -3000.0, 500.0)),
+    (30.0, (0.0, 0.0, 0.0)),                   # edges of ~10 units: the boxes grow by more than the mesh's size
+])
+def test_hierarchy_on_scaled_meshes_matches_oracle(scale, offset):
+    from weekend_raytracer import main
+    scene = mesh_scene(scale, np.array(offset))
+    w, h, s, b = 60, 40, 3, 8
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    main_hierarchy = main.HIERARCHY
+    main.HIERARCHY = 16
+    try:
+        got = main.render_frame(objs, w, h, s, b, seed=11, want_paths=True)
+    finally:
+        main.HIERARCHY = main_hierarchy
+    want = numpy_path.render(scene, w, h, s, b, seed=11)
+    assert np.array_equal(got["path_colours"], want["path_colours"])
+    assert np.array_equal(got["counts"], want["counts"])
+
+
+def awkward_rays(pt0, A, B, rng, n_random):
+    """Rays that stress the box tests: axis-parallel directions (zero components, both signs of zero),
+    origins on the surfaces, rays through corners and along edges, grazing rays in triangle planes."""
+    lo, hi = pt0.min(axis=0) - 1.0, pt0.max(axis=0) + 1.0
+    o = [rng.uniform(lo, hi, (n_random, 3))]
+    d = [rng.normal(size=(n_random, 3))]
+    pick = rng.integers(0, len(pt0), 400)
+    corner = pt0[pick]
+    inside = pt0[pick] + 0.3 * A[pick] + 0.3 * B[pick]
+    start = rng.uniform(lo, hi, (400, 3))
+    o += [start, start]                                   # towards corners and interior points
+    d += [corner - start, inside - start]
+    o += [inside, corner]                                 # starting on a surface / a corner
+    d += [rng.normal(size=(400, 3)), rng.normal(size=(400, 3))]
+    o += [corner - 2.0 * A[pick], inside - 1.5 * (A[pick] + 0.2 * B[pick])]   # along an edge, in the plane
+    d += [A[pick], A[pick] + 0.2 * B[pick]]
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            for zero in (0.0, -0.0):
+                dirs = np.full((300, 3), zero)
+                dirs[:, axis] = sign
+                origin = inside[:300].copy()
+                origin[:, axis] -= sign * 3.0
+                o.append(origin)
+                d.append(dirs)
+                o.append(rng.uniform(lo, hi, (300, 3)))
+                d.append(dirs)
+    o, d = np.concatenate(o), np.concatenate(d)
+    d[:n_random] /= np.linalg.norm(d[:n_random], axis=1)[:, None]
+    return o.astype(np.single), d.astype(np.single)
+
+
+@pytest.mark.parametrize("name", ["ray_group_triangle_group_bunny_scene", "cow_teapot_field_scene"])
+def test_single_rays_hit_the_same_triangle(name):
+    from weekend_raytracer import main, scenes
+    objs = scene_objects(getattr(scenes, name), 16 / 9)
+    rng = np.random.default_rng(5)
+    groups = [g for g in objs[1] if hasattr(g, "pt0s") and len(g.pt0s) >= 64]
+    assert groups
+    g = groups[0]
+    o, d = awkward_rays(np.asarray(g.pt0s), np.asarray(g.As), np.asarray(g.Bs), rng, 20000)
+    res = []
+    for hierarchy in (True, False):
+        frame = main.Frame(objs, hierarchy=16 if hierarchy else 0)
+        frame.ctx.stats_reset()
+        res.append(frame.ctx.intersect(-1, o, d, np.single(0.001), np.single(1000.0)))
+        frame.ctx.close()
+    on, off = res
+    assert off["hit"].mean() > 0.2
+    for key in ("hit", "group", "prim", "back", "mat"):
+        assert np.array_equal(on[key], off[key]), key
+    for key in ("t", "p", "n", "uv"):
+        assert np.array_equal(on[key].view(np.uint32), off[key].view(np.uint32)), key
