@@ -173,8 +173,12 @@ def main():
     ap.add_argument("--hierarchy", action="store_true",
                     help="optional mode, not the reference's algorithm: large triangle groups are walked through a box "
                          "hierarchy; same image bit for bit, and a figure to be read apart from the brute-force one")
+    ap.add_argument("--hierarchy-from", type=int, default=0, metavar="N",
+                    help="like --hierarchy, for groups of N or more triangles (default threshold: 1024)")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
+    if args.hierarchy_from:
+        args.hierarchy = args.hierarchy_from
 
     import torch
     import torch.distributed as dist
@@ -286,7 +290,7 @@ def main():
                 "parallelism": f"samples sharded over {world} GPU(s), RCCL all-reduce of the fp32 image"
                                if world > 1 else "single GPU",
                 "non_finite_pixels": bad_pixels,
-                "triangle_hierarchy": bool(args.hierarchy),
+                "triangle_hierarchy": args.hierarchy,
             },
             "roofline": {
                 "bound": "valu",

@@ -2,15 +2,18 @@
 meant to give the same results must print the same sums.
 
     WRT_LIB=raytracing-one-weekend_amd/lib/libwrt_other.so python tools/frame_checksum.py cover bunny
+
+WRT_HIERARCHY=n walks triangle groups of n or more triangles through their box hierarchies (same sums).
 """
-import sys, hashlib
+import os, sys, hashlib
 sys.path.insert(0, "."); sys.path.insert(0, "raytracing-one-weekend_amd")
 import torch, bench
 from weekend_raytracer import main as wr_main
 for name in sys.argv[1:]:
     kind, width, height, spp, bounces, _, desc = bench.WORKLOADS[name]
     if name == "cow_teapot": width, height, spp = 960, 540, 4
-    frame = wr_main.Frame(bench.build_scene(kind, width / height), device=0)
+    frame = wr_main.Frame(bench.build_scene(kind, width / height), device=0,
+                          hierarchy=int(os.environ.get("WRT_HIERARCHY", "0")))
     paths = torch.full((width * height * spp, 4), -7.0, dtype=torch.float32, device="cuda")
     frame.accumulate(width, height, 0, spp, bounces, 1234, paths=paths)
     torch.cuda.synchronize()

@@ -17,7 +17,11 @@ from weekend_raytracer import main as wr_main  # noqa: E402
 
 def run(name):
     kind, width, height, spp, bounces, _, desc = bench.WORKLOADS[name]
-    frame = wr_main.Frame(bench.build_scene(kind, width / height), device=0)
+    spp = int(os.environ.get("WRT_SPP", spp))
+    # WRT_HIERARCHY=n: groups of n or more triangles are walked through their hierarchies (the walks
+    # are tallied with the triangle loops)
+    frame = wr_main.Frame(bench.build_scene(kind, width / height), device=0,
+                          hierarchy=int(os.environ.get("WRT_HIERARCHY", "0")))
     ctx = frame.ctx
     accum = ctx.zeros((width, height, 3), torch.float32)
     frame.accumulate(width, height, 0, spp, bounces, 1234, accum=accum)
