@@ -138,6 +138,9 @@ class Context:
             raise NativeError(f"wrt_create: {self.lib.wrt_last_error(None).decode()}")
         self.handle = handle
         self.scene_token = None
+        preset = int(os.environ.get("WRT_HIERARCHY", "0"))     # see main.HIERARCHY
+        if preset:
+            self.set_hierarchy(preset)
 
     def close(self):
         if getattr(self, "handle", None):

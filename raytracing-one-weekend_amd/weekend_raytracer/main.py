@@ -23,8 +23,10 @@ T_MAX = 1000.0
 # key of the random streams (the reference uses unseeded generators, main.py:23)
 SEED = 0
 # Optional, not in the reference: walk large triangle groups through a box hierarchy instead of
-# examining every (ray, triangle) pair.  Same image bit for bit, less work.
-HIERARCHY = False
+# examining every (ray, triangle) pair.  Same image bit for bit, less work.  True: groups of 1024 or
+# more triangles; an int: groups of that many or more.  WRT_HIERARCHY in the environment presets it
+# (the whole GPU test suite must pass with WRT_HIERARCHY=16 as it does without); None leaves that preset.
+HIERARCHY = None
 
 # scene rendered by render(); the reference selects it by editing main.py:79-91
 SCENE = scenes.ray_group_triangle_group_bunny_scene
@@ -36,7 +38,9 @@ class Frame():
     def __init__(self, scene, device=None, hierarchy=None):
         camera, groups, material_map = scene
         self.ctx = _native.Context(device)
-        self.ctx.set_hierarchy(HIERARCHY if hierarchy is None else hierarchy)
+        hierarchy = HIERARCHY if hierarchy is None else hierarchy
+        if hierarchy is not None:
+            self.ctx.set_hierarchy(hierarchy)
         self.ctx.upload(_flatten.flatten(camera, groups, material_map, HORIZON_COLOUR, SKY_COLOUR))
 
     def accumulate(self, width, height, s_begin, s_end, max_bounces, seed, accum=None, paths=None):

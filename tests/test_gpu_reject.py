@@ -23,7 +23,7 @@ def both_ways(objs, w, h, s, b, seed):
     from weekend_raytracer import main
     out = []
     for reject in (True, False):
-        frame = main.Frame(objs)
+        frame = main.Frame(objs, hierarchy=0)        # the loops themselves, whatever WRT_HIERARCHY presets
         frame.ctx.set_triangle_reject(reject)
         frame.ctx.stats_reset()
         paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
