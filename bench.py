@@ -312,6 +312,13 @@ def main():
                 "pairs_per_launch": {"triangle": stats["triangle_pairs"] // max(1, launches),
                                      "sphere": stats["sphere_pairs"] // max(1, launches),
                                      "cull": stats["cull_tests"] // max(1, launches)},
+                # the same launch against the HBM roofline: SURVEY-style algorithmic bytes (48 B of ray state per
+                # segment as the reference moves it, 12 B accumulated per primary ray); the kernel itself keeps
+                # ray state in registers and writes 16 B per path
+                "hbm_view": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                             "achieved": round(float(48.0 * segments + 12.0 * float(stats["rays_per_bounce"][0])) /
+                                               (kernel_ms * 1e-3) / 1e9, 2)
+                             if kernel_ms > 0 else 0.0},
                 "lane_efficiency": {
                     "triangle_loops": round(stats["triangle_pairs"] / stats["triangle_lane_slots"], 4)
                     if stats["triangle_lane_slots"] else None,
