@@ -843,7 +843,9 @@ __device__ __forceinline__ bool tree_box(const TreeRay& k, float lox, float loy,
     const float z1 = __builtin_fmaf(loz - grow, k.iz, k.mz), z2 = __builtin_fmaf(hiz + grow, k.iz, k.mz);
     t_near = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
     const float t_far = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
-    return fmaxf(t_near * 0.999999f, t_min) <= fminf(t_far * 1.000001f, upper);
+    // the ends moved outwards by their relative error, whatever their sign (t_min may be negative)
+    return fmaxf(__builtin_fmaf(-1.0e-6f, fabsf(t_near), t_near), t_min) <=
+           fminf(__builtin_fmaf(1.0e-6f, fabsf(t_far), t_far), upper);
 }
 
 // A node is 4 x f32x4: (lo0.xyz, hi0.x) (hi0.yz, lo1.xy) (lo1.z, hi1.xyz) (kappa0, kappa1, child0, child1),
