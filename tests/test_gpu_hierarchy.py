@@ -132,3 +132,56 @@ def test_single_rays_hit_the_same_triangle(name):
         assert np.array_equal(on[key], off[key]), key
     for key in ("t", "p", "n", "uv"):
         assert np.array_equal(on[key].view(np.uint32), off[key].view(np.uint32)), key
+
+
+def test_rays_outside_the_walks_range_fall_back():
+    """Origins beyond 1e9, directions shorter than 1e-9 or longer than 1e9 and NaN rays are outside the
+    range the box growth is proven for: their wavefronts go through the loops, with the same answers."""
+    from weekend_raytracer import main
+    scene = mesh_scene(1.0, np.zeros(3))
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    rng = np.random.default_rng(9)
+    n = 4096
+    o = rng.uniform(-3, 3, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    far = rng.integers(0, n, 40)
+    o[far] = -d[far] * 3.0e9                       # aimed at the mesh from 3e9 away
+    d[rng.integers(0, n, 40)] *= 1.0e-10
+    d[rng.integers(0, n, 40)] *= 1.0e10
+    d[rng.integers(0, n, 20), 1] = np.nan
+    o[rng.integers(0, n, 20), 0] = np.inf
+    o, d = o.astype(np.single), d.astype(np.single)
+    res = []
+    for hierarchy in (16, 0):
+        frame = main.Frame(objs, hierarchy=hierarchy)
+        res.append(frame.ctx.intersect(-1, o, d, np.single(0.001), np.single(1000.0)))
+        frame.ctx.close()
+    on, off = res
+    assert 0.05 < off["hit"].mean() < 0.95
+    for key in ("hit", "group", "prim", "back", "mat"):
+        assert np.array_equal(on[key], off[key]), key
+    for key in ("t", "p", "n", "uv"):
+        assert np.array_equal(on[key].view(np.uint32), off[key].view(np.uint32)), key
+
+
+def test_meshes_the_builder_declines():
+    """A group with a corner that is not finite gets no hierarchy (the loops handle it as before); a group
+    with triangles of zero area gets one."""
+    from weekend_raytracer import main
+    for spoil in ("nan", "flat"):
+        scene = mesh_scene(1.0, np.zeros(3))
+        tris = scene["groups"][1]
+        if spoil == "nan":
+            tris["A"] = tris["A"].copy()
+            tris["A"][7, 1] = np.nan
+        else:
+            tris["B"] = tris["B"].copy()
+            tris["B"][5] = tris["A"][5] * 2.0          # B parallel to A: zero area
+            tris["A"][9] = 0.0                         # a point
+        objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+                {i: Flat(m) for i, m in scene["materials"].items()})
+        (p_on, st_on), (p_off, st_off) = both_ways(objs, 60, 40, 2, 6, seed=3)
+        assert np.array_equal(p_on.view(np.uint32), p_off.view(np.uint32))
+        assert st_on["triangle_pairs"] == st_off["triangle_pairs"]
