@@ -372,7 +372,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                 pc.triangle += (unsigned long long)run_n * (unsigned)count;
                 pc.triangle_slots += 64ull * (unsigned)count;
                 const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach,
-                                                           ugroups[run_g].radius_max, ugroups[run_g].c[0],
+                                                           ugroups[run_g].reject_eps, ugroups[run_g].c[0],
                                                            ugroups[run_g].c[1], ugroups[run_g].c[2]);
                 bool walked = false;
                 if (WALK && S.hierarchy != 0 && ugroups[run_g].tree_base >= 0 && count >= S.hierarchy) {
@@ -837,11 +837,15 @@ int wrt_set_sky(wrt_ctx* ctx, const float horizon[3], const float zenith[3]) {
 // triangles per record, padded to whole blocks of 16 with the group's last triangle; the group's
 // largest edge component and largest coordinate offset from the group's bounding-sphere centre for
 // the error bounds of the reject test.
+#ifndef WRT_REJECT_EPS_SCALE
+#define WRT_REJECT_EPS_SCALE 8.0      // measured: 6 to 12 are equally good, rays far from head-on weigh more than the estimate assumes
+#endif
+static constexpr double REJECT_EPS_SCALE = WRT_REJECT_EPS_SCALE;
 static void build_bounds(wrt_ctx* ctx) {
     ctx->h_bounds.clear();
     for (GroupRec& g : ctx->h_groups) {
         g.bound_base = (int)ctx->h_bounds.size();
-        g.edge_max = 0.0f; g.reach = 0.0f; g.radius_max = 0.0f;
+        g.edge_max = 0.0f; g.reach = 0.0f; g.reject_eps = 0.5f;
         if (g.type != GROUP_TRIANGLES) continue;
         const int padded = (g.count + 15) & ~15;
         std::vector<float> cx(padded), cy(padded), cz(padded), rr(padded), nx(padded), ny(padded), nz(padded);
@@ -899,16 +903,29 @@ static void build_bounds(wrt_ctx* ctx) {
         }
         g.edge_max = std::nextafter((float)edge_max, INFINITY);
         g.reach = std::nextafter((float)reach, INFINITY);
-        float radius_max = 0.0f;
+        // eps of the reject test (any positive value is safe): what balances eps r^2 against rho^2 / eps for a
+        // triangle of median radius and area seen head-on from four times the group's extent away
+        {
+            std::vector<float> radii(rr.begin(), rr.begin() + g.count), areas((size_t)g.count);
+            for (int j = 0; j < g.count; ++j)
+                areas[(size_t)j] = std::sqrt(nx[j] * nx[j] + ny[j] * ny[j] + nz[j] * nz[j]);
+            std::nth_element(radii.begin(), radii.begin() + g.count / 2, radii.end());
+            std::nth_element(areas.begin(), areas.begin() + g.count / 2, areas.end());
+            const double r_mid = radii[(size_t)(g.count / 2)], n_mid = areas[(size_t)(g.count / 2)];
+            const double rho = 2.6e-5 * edge_max * edge_max * (4.0 * reach + edge_max) / std::max(0.5 * n_mid, 1e-5);
+            double eps = r_mid > 0.0 ? REJECT_EPS_SCALE * rho / r_mid : 0.5;
+            if (!(eps >= 0.01)) eps = 0.01;
+            if (eps > 0.5) eps = 0.5;
+            g.reject_eps = (float)eps;
+        }
         for (int j = 0; j < padded; ++j) {
             // rounding of the radius itself and the 9e-7 M term of the bound
             const float r = std::nextafter((float)((double)rr[j] * (1.0 + 1e-6) + 1e-6 * edge_max), INFINITY);
-            radius_max = std::max(radius_max, r);
-            // the test's constant |c'|^2 - r^2, rounded down
-            const double k = ((double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j]) - (double)r * r;
+            // the test's constant |c'|^2 - (1 + eps) r^2, rounded down
+            const double k = ((double)cx[j] * cx[j] + (double)cy[j] * cy[j] + (double)cz[j] * cz[j]) -
+                             (1.0 + (double)g.reject_eps) * (1.0 + 1e-7) * (double)r * r;
             rr[j] = std::nextafter((float)k, -INFINITY);
         }
-        g.radius_max = radius_max;
         for (int j = 0; j < padded; j += 2) {
             ctx->h_bounds.push_back(f32x4{cx[j], cx[j + 1], cy[j], cy[j + 1]});
             ctx->h_bounds.push_back(f32x4{cz[j], cz[j + 1], rr[j], rr[j + 1]});

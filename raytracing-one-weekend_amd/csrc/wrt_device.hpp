@@ -39,7 +39,7 @@ struct GroupRec {            // 112 bytes, uniform
     float edge_max;          // triangles: largest |component| of any edge vector A, B of the group
     float reach;             // triangles: largest |coordinate - c| of any corner or bounding-sphere centre
     int slot;                // large groups: bit of the render kernel's pending mask, -1 = none
-    float radius_max;        // triangles: largest radius of the bounding records
+    float reject_eps;        // triangles: eps of the reject test, as used for the bounding records' k
     int tree_base;           // triangles: first f32x4 of the group's box hierarchy, -1 = none
     float reach2;            // triangles with a hierarchy: largest distance of any corner from c
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
@@ -604,10 +604,18 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 // bounding-sphere centre g: with o' = o - g per lane and c' = c - g per triangle,
 //     |d|^2 ((r + rho)^2 - |co|^2) + (d.co)^2
 //         = (d.o' - d.c')^2 + |d|^2 ((2 o'.c' - |o'|^2) - (|c'|^2 - r^2) + rho (2 r + rho)),
-// two fused chains from per-lane starts, the per-triangle constant k = |c'|^2 - r^2, and
-// rho (2 r + rho) <= inv (w2 + w3 inv) with inv = 1 / max(|det'|, 1e-5) and the per-lane numbers
-// w2 = 2 r_max widen, w3 = widen^2 (r_max: the group's largest radius).  Its float32 error is at
-// most 30u |d|^2 S^2 + 4u |d|^2 r^2 with S = |o'| + |c'| <= sqrt(3) T: below `slack`.
+// two fused chains from per-lane starts and a per-triangle constant.  No reciprocal is taken:
+// with rho = widen / D, D = max(|det'|, 1e-5),
+//     rho (2 r + rho) <= eps r^2 + (1 + 1/eps) rho^2        (2 r rho <= eps r^2 + rho^2 / eps),
+//     1 / D^2 <= 2 / E,  E = det'^2 + 1e-10                  (a maximum is at least the mean),
+// so the line is near enough whenever  Q E + W >= 0  with
+//     Q = (d.o' - d.c')^2 + |d|^2 ((2 o'.c' - |o'|^2) - k) + slack,   k = |c'|^2 - (1 + eps) r^2,
+//     W = 2 (1 + 1/eps) |d|^2 widen^2,
+// fourteen packed instructions for two triangles.  eps is chosen per group by the host (any positive
+// value is safe): 0.05 lets 5 % more squared radius through and pays for rays close to a triangle's
+// plane with 42 rho^2 instead of rho (2 r + rho).  The float32 error of Q is at most 30u |d|^2 S^2 + 4u |d|^2 r^2 with
+// S = |o'| + |c'| <= sqrt(3) T: below `slack`; E and the last operation err by a few u relatively, W is
+// taken 1e-5 too large for them.
 struct BoundPair { f32x2 cx, cy, cz, k, nx, ny, nz; };                // 4 x f32x4 (last two floats unused)
 __device__ __forceinline__ BoundPair fetch_bound_pair(const WRT_CONST f32x4* p) {
     const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
@@ -618,13 +626,14 @@ struct SphereReject {
     f32x2 ox2, oy2, oz2, dx, dy, dz;   // 2 o' and d, each number in both halves
     f32x2 d_o, minus_oo;               // d.o', -|o'|^2
     f32x2 dd;                          // |d|^2
-    f32x2 w2, w3;                      // 2 r_max widen and widen^2, widen = 2 * 208u D M^2 (T + M), rounded up
+    f32x2 W;                           // 2 (1 + 1/eps) |d|^2 widen^2, widen = 2 * 208u D M^2 (T + M), rounded up
+    f32x2 floor2;                      // 1e-10 in both halves
     f32x2 slack;     // float32 error allowance of the test; -inf for lanes that ride along
     bool usable;     // the bounds of the error analysis hold for this lane
     bool active;     // the lane's ray is at this group
 };
 __device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool active, float edge_max, float reach,
-                                                            float radius_max, float gx, float gy, float gz) {
+                                                            float eps, float gx, float gy, float gz) {
     SphereReject k;
     k.active = active;
     const float D = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz));
@@ -636,12 +645,12 @@ __device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool a
     const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
     const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
     const float widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
-    const float w2 = 2.000004f * radius_max * widen, w3 = 1.000004f * widen * widen;
+    const float W = (2.00002f * (1.0f + 1.0f / eps)) * dd * (widen * widen);
     const float slack = active ? 3.9e-6f * dd * (3.0f * T * T) + 1.0e-30f : -__builtin_inff();
     k.ox2 = f32x2{2.0f * ox, 2.0f * ox}; k.oy2 = f32x2{2.0f * oy, 2.0f * oy}; k.oz2 = f32x2{2.0f * oz, 2.0f * oz};
     k.dx = f32x2{r.dx, r.dx}; k.dy = f32x2{r.dy, r.dy}; k.dz = f32x2{r.dz, r.dz};
     k.d_o = f32x2{d_o, d_o}; k.minus_oo = f32x2{-oo, -oo}; k.dd = f32x2{dd, dd};
-    k.w2 = f32x2{w2, w2}; k.w3 = f32x2{w3, w3}; k.slack = f32x2{slack, slack};
+    k.W = f32x2{W, W}; k.floor2 = f32x2{1.0e-10f, 1.0e-10f}; k.slack = f32x2{slack, slack};
     // written so that a NaN or infinite ray is not usable
     k.usable = !active || (D * edge_max * edge_max <= 2.5f && T <= 1.0e15f);
     return k;
@@ -654,12 +663,9 @@ __device__ __forceinline__ f32x2 sphere_reject2(const SphereReject& r, const Bou
     const f32x2 m = __builtin_elementwise_fma(r.oz2, b.cz, __builtin_elementwise_fma(r.oy2, b.cy,
                         __builtin_elementwise_fma(r.ox2, b.cx, r.minus_oo))) - b.k;          // r^2 - |co|^2
     const f32x2 det = __builtin_elementwise_fma(r.dz, b.nz, __builtin_elementwise_fma(r.dy, b.ny, r.dx * b.nx));
-    const f32x2 inv = {__builtin_amdgcn_rcpf(fmaxf(fabsf(det.x), 0.00001f)),
-                       __builtin_amdgcn_rcpf(fmaxf(fabsf(det.y), 0.00001f))};
-    const f32x2 grow = __builtin_elementwise_fma(r.w3, inv, r.w2);        // rho (2 r + rho) <= inv * grow
-    const f32x2 v = __builtin_elementwise_fma(grow, inv, m);
-    const f32x2 t2 = __builtin_elementwise_fma(r.dd, v, r.slack);
-    return __builtin_elementwise_fma(-h, h, -t2);                         // < 0: the line comes near enough
+    const f32x2 E = __builtin_elementwise_fma(det, det, r.floor2);
+    const f32x2 Q = __builtin_elementwise_fma(h, h, __builtin_elementwise_fma(r.dd, m, r.slack));
+    return __builtin_elementwise_fma(-Q, E, -r.W);                        // sign set: the line comes near enough
 }
 
 // triangle_group.py:302-399 for the triangles each lane noted, lowest index first
@@ -979,7 +985,7 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
             pc.triangle += (unsigned long long)__popcll(pass_mask) * (unsigned)count;
             pc.triangle_slots += 64ull * (unsigned)count;
             const SphereReject k = sphere_reject_setup(r, pass, groups[g].edge_max, groups[g].reach,
-                                                       groups[g].radius_max, groups[g].c[0], groups[g].c[1],
+                                                       groups[g].reject_eps, groups[g].c[0], groups[g].c[1],
                                                        groups[g].c[2]);
             bool walked = false;
             if (S.hierarchy != 0 && groups[g].tree_base >= 0 && count >= S.hierarchy) {
