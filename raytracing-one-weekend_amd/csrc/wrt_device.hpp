@@ -610,13 +610,13 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 // a square, one fused chain of four from a per-lane start, and a per-triangle constant k.  No reciprocal is taken:
 // with rho = widen / D, D = max(|det'|, 1e-5),
 //     rho (2 r + rho) <= eps r^2 + (1 + 1/eps) rho^2        (2 r rho <= eps r^2 + rho^2 / eps),
-//     1 / D^2 <= 2 / E,  E = det'^2 + 1e-10                  (a maximum is at least the mean),
+//     1 / D^2 <= 1 / E,  E = det'^2                          (for |det'| < 1e-5 the floor only makes D larger),
 // so the line is near enough whenever  Q E + W >= 0  with
 //     Q = (d.o' - d.c')^2 + |d|^2 ((2 o'.c' - |o'|^2) - k) + slack,   k = |c'|^2 - (1 + eps) r^2,
-//     W = 2 (1 + 1/eps) |d|^2 widen^2,
+//     W = (1 + 1/eps) |d|^2 widen^2,
 // thirteen packed instructions for two triangles.  eps is chosen per group by the host (any positive
 // value is safe): 0.05 lets 5 % more squared radius through and pays for rays close to a triangle's
-// plane with 42 rho^2 instead of rho (2 r + rho).  The float32 error of Q (roundings of v: 8.3u, of s: 12u, of the
+// plane with 21 rho^2 instead of rho (2 r + rho).  The float32 error of Q (roundings of v: 8.3u, of s: 12u, of the
 // square: 7u, of the chain and k: 11u, of o - g: 4u, each times |d|^2 S^2) is at most 43u |d|^2 S^2 + u |d|^2 r^2
 // with S = |o'| + |c'| <= sqrt(3) T: below `slack` = 65u |d|^2 (3 T^2); E and the last operation err by a few u relatively, W is
 // taken 1e-5 too large for them.
@@ -631,8 +631,7 @@ struct SphereReject {
     f32x2 vx, vy, vz;                  // 2 (|d|^2 o' - (d.o') d)
     f32x2 s0;                          // (d.o')^2 - |d|^2 |o'|^2 + slack; -inf for lanes that ride along
     f32x2 minus_dd;                    // -|d|^2
-    f32x2 W;                           // 2 (1 + 1/eps) |d|^2 widen^2, widen = 2 * 208u D M^2 (T + M), rounded up
-    f32x2 floor2;                      // 1e-10 in both halves
+    f32x2 W;                           // (1 + 1/eps) |d|^2 widen^2, widen = 2 * 208u D M^2 (T + M), rounded up
     bool usable;     // the bounds of the error analysis hold for this lane
     bool active;     // the lane's ray is at this group
 };
@@ -649,14 +648,14 @@ __device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool a
     const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
     const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
     const float widen = 2.6e-5f * D * edge_max * edge_max * (T + edge_max);
-    const float W = (2.00002f * (1.0f + 1.0f / eps)) * dd * (widen * widen);
+    const float W = (1.00002f * (1.0f + 1.0f / eps)) * dd * (widen * widen);
     const float slack = active ? 3.9e-6f * dd * (3.0f * T * T) + 1.0e-30f : -__builtin_inff();
     const float vx = 2.0f * (dd * ox - d_o * r.dx), vy = 2.0f * (dd * oy - d_o * r.dy), vz = 2.0f * (dd * oz - d_o * r.dz);
     const float s0 = (d_o * d_o - dd * oo) + slack;
     k.dx = f32x2{r.dx, r.dx}; k.dy = f32x2{r.dy, r.dy}; k.dz = f32x2{r.dz, r.dz};
     k.vx = f32x2{vx, vx}; k.vy = f32x2{vy, vy}; k.vz = f32x2{vz, vz};
     k.s0 = f32x2{s0, s0}; k.minus_dd = f32x2{-dd, -dd};
-    k.W = f32x2{W, W}; k.floor2 = f32x2{1.0e-10f, 1.0e-10f};
+    k.W = f32x2{W, W};
     // written so that a NaN or infinite ray is not usable
     k.usable = !active || (D * edge_max * edge_max <= 2.5f && T <= 1.0e15f && dd * (T * T) <= 1.0e30f);
     return k;
@@ -669,7 +668,7 @@ __device__ __forceinline__ f32x2 sphere_reject2(const SphereReject& r, const Bou
                         __builtin_elementwise_fma(r.vy, b.cy, __builtin_elementwise_fma(r.vx, b.cx, r.s0))));
     const f32x2 Q = __builtin_elementwise_fma(g, g, t);
     const f32x2 det = __builtin_elementwise_fma(r.dz, b.nz, __builtin_elementwise_fma(r.dy, b.ny, r.dx * b.nx));
-    const f32x2 E = __builtin_elementwise_fma(det, det, r.floor2);
+    const f32x2 E = det * det;
     return __builtin_elementwise_fma(-Q, E, -r.W);                        // sign set: the line comes near enough
 }
 
