@@ -18,7 +18,7 @@ FP32 vector peak with the algorithmic flop count of the reference's dense
 evaluation (45 per ray-triangle pair after the cull, 19 per ray-sphere pair,
 14 per bounding-sphere test); `roofline.executed` is the arithmetic the kernel
 really issues for those pairs (a conservative 15-flop bound per sphere pair, a
-28-flop bounding-sphere test per triangle pair, the reference's full
+23-flop bounding-sphere test per triangle pair, the reference's full
 evaluation only for the pairs that survive).  `--full-evaluation` switches the
 triangle reject off, so that every pair gets the reference's arithmetic.
 `cpu_baseline` times the CPU restatement of the reference's numpy path
@@ -92,7 +92,7 @@ def flop_counts(stats, hierarchy=False):
     algorithmic: what the reference evaluates for these pairs (triangle_group.py:289-395 45 flop,
     sphere_group.py:137-205 19 flop, triangle_group.py:158-166 14 flop).  executed: what the kernel
     issues: spheres meet a 15-flop bound of the discriminant, the full 19 only for candidates (not
-    counted); triangles of large groups meet a 28-flop bounding-sphere test and the 45-flop evaluation
+    counted); triangles of large groups meet a 23-flop bounding-sphere test and the 45-flop evaluation
     only if they survive it; with the reject off (or in small groups) every pair costs 45 + 10 filter flops.
     With hierarchy=True (--hierarchy) "algorithmic" still counts the pairs the reference would examine,
     so the fraction built on it is a speed-up figure, not a utilisation.
@@ -100,7 +100,7 @@ def flop_counts(stats, hierarchy=False):
     tri, sph, cull = stats["triangle_pairs"], stats["sphere_pairs"], stats["cull_tests"]
     algorithmic = 45.0 * tri + 19.0 * sph + 14.0 * cull
     evaluated = stats["triangle_evaluations"]
-    executed_tri = 28.0 * tri + 45.0 * evaluated if evaluated else 55.0 * tri
+    executed_tri = 23.0 * tri + 45.0 * evaluated if evaluated else 55.0 * tri
     if hierarchy:
         # only the leaf triangles a walk looked at (box tests are not counted): pairs of groups too small
         # for a hierarchy are missing from this figure, it is a lower bound
