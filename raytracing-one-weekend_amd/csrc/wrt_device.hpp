@@ -361,7 +361,10 @@ enum { SHARE_ITEMS = 384 };
 #ifndef WRT_TIMING
 #define WRT_TIMING 0
 #endif
-#if WRT_TIMING
+#if defined(WRT_DRAIN_COUNT)
+#define WRT_DRAIN_BEGIN(q) ((void)0)
+#define WRT_DRAIN_END(q) ((q).drain_ticks += 1)
+#elif WRT_TIMING
 #define WRT_DRAIN_BEGIN(q) const long long drain_began = (long long)__builtin_readcyclecounter()
 #define WRT_DRAIN_END(q) ((q).drain_ticks += (long long)__builtin_readcyclecounter() - drain_began)
 #else
@@ -710,19 +713,24 @@ __device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, 
                                      (best.group > g ? 0xffffffffull : 0ull);
     q.share_best[lane] = start;
     for (int chunk = 0; chunk < total; chunk += SHARE_ITEMS) {
-        // owners write their items of this chunk, entry by entry, lowest index first
+        // owners write their items of this chunk, one a trip, each lane going through its own
+        // entries at its own pace (a stored entry has a bit set)
         int number = before - chunk;
-        for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
-            const unsigned entry = (k < q.n) ? q.slot[k * 64] : 0u;
-            unsigned open = entry & 0xffffu;
-            const unsigned tagged_first = (lane << 24) | (16u * (entry >> 16) + 15u);
-            while (__ballot(open != 0u) != 0ull) {
-                if (open != 0u) {
-                    const unsigned bit = 31u - (unsigned)__builtin_clz(open);
-                    open &= ~(1u << bit);
-                    if ((unsigned)number < (unsigned)SHARE_ITEMS) q.share_list[number] = tagged_first - bit;
-                    ++number;
-                }
+        int k = 0;
+        unsigned open = 0u, tagged_first = 0u;
+        for (;;) {
+            if (open == 0u && k < q.n) {
+                const unsigned entry = q.slot[k * 64];
+                ++k;
+                open = entry & 0xffffu;
+                tagged_first = (lane << 24) | (16u * (entry >> 16) + 15u);
+            }
+            if (__ballot(open != 0u) == 0ull) break;
+            if (open != 0u) {
+                const unsigned bit = 31u - (unsigned)__builtin_clz(open);
+                open &= ~(1u << bit);
+                if ((unsigned)number < (unsigned)SHARE_ITEMS) q.share_list[number] = tagged_first - bit;
+                ++number;
             }
         }
         const int items = total - chunk < SHARE_ITEMS ? total - chunk : SHARE_ITEMS;
