@@ -10,8 +10,13 @@ One "step" is one full frame of the workload: the persistent bounce kernel
 over all pixels x samples, the per-pixel sample reduction, (N > 1) the RCCL
 all-reduce of the float32 accumulation images, and the sqrt/mean finalise.
 The scene is resident in HBM before timing starts.  With N > 1 every rank
-renders its own `spp` samples of every pixel (disjoint global sample indices:
-weak scaling) and the images are summed over xGMI.
+renders its own samples of every pixel (disjoint global sample indices) and the
+images are summed over xGMI: `--scaling weak` (default) gives every rank the
+workload's spp, `--scaling strong` splits the workload's spp over the ranks.
+
+Started without torch.distributed.run (`python bench.py --gpus N`, N > 1), the
+process starts N child ranks of itself before it touches the GPU, relays rank
+0's JSON line and exits with the children's status.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the bounce kernel against the
 FP32 vector peak with the algorithmic flop count of the reference's dense
@@ -158,6 +163,57 @@ def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True, hi
     return out
 
 
+def launch_ranks(n_ranks, argv):
+    """Start `n_ranks` copies of this script as the ranks of one job (the environment
+    torch.distributed.run would give them) from a parent that has made no GPU call; relay rank 0's
+    stdout; -> the first non-zero exit status of a rank, else 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    ranks = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        ranks.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    status = 0
+    try:
+        for line in ranks[0].stdout:                 # rank 0 prints the one JSON line
+            sys.stdout.write(line.decode())
+            sys.stdout.flush()
+        for proc in ranks:
+            rc = proc.wait()
+            if rc != 0 and status == 0:
+                status = rc
+                for other in ranks:                  # a failed rank leaves the others waiting in a collective
+                    if other.poll() is None:
+                        other.terminate()
+    finally:
+        for proc in ranks:
+            if proc.poll() is None:
+                proc.kill()
+    return status
+
+
+def launch_check(world, rank, backend):
+    """--launch-check: the ranks meet, count themselves over the backend and leave (no rendering);
+    what the CPU test of the launcher runs."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend)
+    seen = torch.ones(1, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "ranks_seen": int(seen.item()), "n_gpus": world}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,24 +232,33 @@ def main():
     ap.add_argument("--hierarchy-from", type=int, default=0, metavar="N",
                     help="like --hierarchy, for groups of N or more triangles (default threshold: 1024)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N > 1: weak = the workload's spp on every GPU; strong = the workload's spp split over the GPUs")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, count them over the backend and stop (tests the launcher; no rendering)")
     args = ap.parse_args()
     if args.hierarchy_from:
         args.hierarchy = args.hierarchy_from
 
-    import torch
-    import torch.distributed as dist
-    from weekend_raytracer import main as wr_main
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-        args.gpus = world
+    args.gpus = world
     # BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 code path on a
     # one-GPU box); the driver's runs use the default: one GPU per rank, RCCL.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if args.launch_check:
+        return launch_check(world, rank, backend)
+
+    import torch
+    import torch.distributed as dist
+    from weekend_raytracer import distributed
+    from weekend_raytracer import main as wr_main
+
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -208,19 +273,31 @@ def main():
     frame = wr_main.Frame(build_scene(kind, width / height), device=local_rank, hierarchy=args.hierarchy)
     ctx = frame.ctx
     ctx.set_triangle_reject(not args.full_evaluation)
-    s_begin = rank * spp                      # weak scaling: disjoint global sample ranges
+    # weak: every rank renders `spp` samples; strong: the `spp` samples are split over the ranks
+    spp_total = spp * world if args.scaling == "weak" else spp
+    if spp_total < world:
+        raise SystemExit(f"--scaling strong: {spp_total} samples per pixel cannot be split over {world} ranks")
+
+    def all_reduce_sum(accum):
+        if world == 1:
+            return
+        if backend == "nccl":
+            dist.all_reduce(accum)
+        else:                                       # gloo rehearsal: reduce through the host
+            host = accum.cpu()
+            dist.all_reduce(host)
+            accum.copy_(host)
+
+    def render_samples(s_begin, s_end):
+        accum = ctx.zeros((width, height, 3), torch.float32)
+        frame.accumulate(width, height, s_begin, s_end, bounces, args.seed, accum=accum)
+        return accum
 
     def step():
-        accum = ctx.zeros((width, height, 3), torch.float32)
-        frame.accumulate(width, height, s_begin, s_begin + spp, bounces, args.seed, accum=accum)
-        if world > 1:
-            if backend == "nccl":
-                dist.all_reduce(accum)
-            else:                                   # gloo rehearsal: reduce through the host
-                host = accum.cpu()
-                dist.all_reduce(host)
-                accum.copy_(host)
-        return frame.image(accum, spp * world)
+        # the package's own multi-GPU routine: this rank's contiguous share of the global sample
+        # indices, one all-reduce of the float32 accumulation images
+        accum = distributed.accumulate_sharded(render_samples, spp_total, rank, world, all_reduce_sum)
+        return frame.image(accum, spp_total)
 
     def fence():
         if world > 1:
@@ -245,16 +322,17 @@ def main():
 
     segments = int(stats["rays_per_bounce"][:bounces].sum())
     flops, executed_flops = flop_counts(stats, args.hierarchy)
-    totals = torch.tensor([float(segments), elapsed], dtype=torch.float64,
+    totals = torch.tensor([float(segments), elapsed, 1.0], dtype=torch.float64,
                           device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
-        seg_sum = totals[0:1].clone()
+        sums = totals.clone()                       # segments and a count of the ranks the collective saw
         t_max = totals[1:2].clone()
-        dist.all_reduce(seg_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        segments_all, elapsed_max = float(seg_sum.item()), float(t_max.item())
+        segments_all, elapsed_max, ranks_seen = float(sums[0].item()), float(t_max.item()), int(sums[2].item())
     else:
-        segments_all, elapsed_max = float(segments), elapsed
+        segments_all, elapsed_max, ranks_seen = float(segments), elapsed, 1
+    s_mine = distributed.shard_samples(spp_total, rank, world)
 
     if rank == 0:
         # The reference's refraction is not renormalised (materials.py:395-398); once in ~3e7 glass paths a
@@ -279,13 +357,15 @@ def main():
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
             "seconds_per_frame": round(elapsed_max / args.steps, 6),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
+            "ranks_seen": ranks_seen,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {desc}", "width": width, "height": height,
-                "spp_per_gpu": spp, "max_bounces": bounces, "seed": args.seed,
+                "spp_per_gpu": s_mine[1] - s_mine[0], "spp_total": spp_total, "max_bounces": bounces,
+                "seed": args.seed, "backend": "rccl" if backend == "nccl" else backend,
                 "segments_per_frame_per_gpu": segments // max(1, args.steps),
                 "parallelism": f"samples sharded over {world} GPU(s), RCCL all-reduce of the fp32 image"
                                if world > 1 else "single GPU",
@@ -342,10 +422,13 @@ def main():
                            # optional mode, reported apart: not the reference's brute-force work
                            "bunny_hierarchy": side_measurement("bunny", args.seed, local_rank, with_cpu=False,
                                                                hierarchy=64),   # below the default threshold of 1024
-                           "cow_teapot_8spp": side_measurement("cow_teapot", args.seed, local_rank, steps=1,
-                                                               with_cpu=False, spp=8),
-                           "cow_teapot_8spp_hierarchy": side_measurement("cow_teapot", args.seed, local_rank, steps=1,
-                                                                         with_cpu=False, hierarchy=True, spp=8)}
+                           # textured bunny + UV-mapped cloth at its stated size
+                           "cloth": side_measurement("cloth", args.seed, local_rank, steps=2, with_cpu=False),
+                           # cow + teapot + sphere field at its stated per-GPU size (3840x2160, 128 spp)
+                           "cow_teapot_128spp": side_measurement("cow_teapot", args.seed, local_rank, steps=1,
+                                                                 with_cpu=False),
+                           "cow_teapot_128spp_hierarchy": side_measurement("cow_teapot", args.seed, local_rank,
+                                                                           steps=1, with_cpu=False, hierarchy=True)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

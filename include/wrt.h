@@ -12,12 +12,18 @@
  *   - every function returns 0 on success and a negative WRT_E_* code on
  *     failure; wrt_last_error() gives the text of the last failure of that
  *     context (or of wrt_create when passed NULL);
- *   - one context per GPU, used by one host thread at a time;
+ *   - one context per GPU, used by one host thread at a time; a call makes the
+ *     context's device current while it runs and puts the caller's back;
  *   - "device pointer" = memory of the context's GPU owned by the caller
  *     (e.g. torch.Tensor.data_ptr()); "host-or-device pointer" = either,
  *     the library copies out of it before returning;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
- *     launches are asynchronous on it, nothing is synchronised unless said;
+ *     launches are asynchronous on it, nothing is synchronised unless said.
+ *     A context's launches share its scene and workspaces: a launch on another
+ *     stream than the context's previous one is ordered behind it on the
+ *     device, and wrt_scene_commit, wrt_set_texture and wrt_destroy wait on
+ *     the host for the context's last launch before they overwrite or free
+ *     what it reads;
  *   - arithmetic follows the reference operation by operation: float32
  *     intersection without fused multiply-adds, float64 scatter arithmetic
  *     on float32 values, same thresholds and tie-breaks.
@@ -45,7 +51,9 @@ enum {
     WRT_MAX_BOUNCES = 62,     /* per-bounce statistics slots */
     WRT_MAX_MATERIALS = 256,  /* uint8 material indices (sphere_group.py:30) */
     WRT_MAX_TEXTURES = 16,
-    WRT_MAX_GROUPS = 4096
+    WRT_MAX_GROUPS = 4096,
+    WRT_MAX_GROUP_TRIANGLES = 1 << 20,   /* per triangle group (split larger meshes into several groups) */
+    WRT_MAX_SCENE_PRIMITIVES = 1 << 26   /* spheres, and triangles, over all groups of a scene */
 };
 
 /* materials.py: one entry per class */
@@ -162,6 +170,13 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
 /* image = sqrt(accum / spp_total)  (main.py:219-220); n_values = width*height*3 */
 int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total,
                  float* image, void* stream);
+
+/* generate_image_from_data (main.py:45-74) without the per-pixel Python loop: image is the
+   [width][height][3] float32 result of wrt_finalize (y = 0 at the bottom), rgb receives
+   [height][width][3] bytes, row 0 at the top, each int(255 * v) as a float32 product truncated
+   towards zero and clipped to 0..255 (what PIL stores for the reference's fill tuple); NaN, on
+   which the reference raises, is stored as 0.  Device pointers. */
+int wrt_image_bytes(wrt_ctx* ctx, const float* image, int width, int height, uint8_t* rgb, void* stream);
 
 /* No counterpart in the reference, which evaluates triangle_group.py:289-395 in full
    for every (ray, triangle) pair.  on = 1 (default): in groups of more than 8 triangles

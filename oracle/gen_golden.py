@@ -437,6 +437,49 @@ def bunny_diffuse_scene(ref, aspect_ratio):
     return cam, groups, material_map
 
 
+def placed_mesh(ref, obj_name, material_id, offset):
+    """A TriangleGroup filled the way the four-bunnies and cow scenes fill theirs (scenes.py:57-190,
+    236-271): vertices lifted to y = 0 and shifted in x and z as Python floats, points made float32."""
+    mesh = ref.obj_tri_mesh.OBJTriMesh()
+    mesh.read(obj_name)
+    smallest_y = min(v[1] for v in mesh.vertices)
+    grp = ref.triangle_group.TriangleGroup(material_id)
+    for tri in mesh.faces:
+        grp.add_triangle(*[numpy.array([mesh.vertices[tri[k][0]][0] + offset[0],
+                                        mesh.vertices[tri[k][0]][1] - smallest_y,
+                                        mesh.vertices[tri[k][0]][2] + offset[1]], dtype=numpy.single)
+                           for k in range(3)])
+    return grp
+
+
+def cow_teapot_field_scene(ref, aspect_ratio, records):
+    """The cow + teapot + sphere-field benchmark configuration (no reference scene uses teapot.obj):
+    the cover scene's spheres and materials without depth of field, the cow scene's mesh material on
+    the cow (scenes.py:196-273), a mirror teapot, both meshes built by the reference's own
+    OBJTriMesh / TriangleGroup.add_triangle."""
+    M = ref.materials
+    _, (spheres,), material_map = cover_scene(ref, aspect_ratio, records)
+    cam = ref.camera.Camera(numpy.array([13.0, 6.0, 9.0]), numpy.array([0.0, 1.5, 0.0]), 10.0, 0.0, aspect_ratio, 40.0)
+    material_map[250] = M.CheckerboardDiffuse(numpy.array([1.0, 1.0, 1.0]), numpy.array([0.2, 0.2, 0.2]),
+                                              numpy.array([0.8, 0.8, 0.85], dtype=numpy.single),
+                                              numpy.array([0.25, 0.25, 0.2], dtype=numpy.single))
+    material_map[251] = M.Metal(numpy.array([0.85, 0.85, 0.85], dtype=numpy.single), 0.0)
+    cow = placed_mesh(ref, "cow.obj", 250, (-3.0, -2.5))
+    teapot = placed_mesh(ref, "teapot.obj", 251, (3.0, 3.5))
+    return cam, [spheres, cow, teapot], material_map
+
+
+def write_smooth_normals(ref, obj_name, every):
+    """OBJTriMesh.get_smooth_vertex_normal (obj_tri_mesh.py:27-68) of every `every`-th vertex of a mesh."""
+    with quiet():
+        mesh = ref.obj_tri_mesh.OBJTriMesh()
+        mesh.read(obj_name)
+        picked = numpy.arange(0, len(mesh.vertices), every)
+        normals = numpy.array([mesh.get_smooth_vertex_normal(int(v)) for v in picked])
+    save("smooth_normals_" + obj_name.split(".")[0], mesh=numpy.array(obj_name), vertices=picked, normals=normals,
+         dtype=numpy.array(str(normals.dtype)))
+
+
 # --------------------------------------------------------------------------
 # fixture writers
 # --------------------------------------------------------------------------
@@ -746,7 +789,7 @@ def write_frame(ref, name, scene_fn, width, height, samples, bounces, seed, text
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="comma list of: check,kat,camera,intersect,scatter,frames,heavy")
+    ap.add_argument("--only", default="", help="comma list of: check,kat,camera,intersect,scatter,frames,heavy,composite")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
 
@@ -797,6 +840,11 @@ def main():
         write_intersect(ref, "cow", S.numpy_cow_scene, width=32, height=18)
         write_frame(ref, "bunnies", S.numpy_bunnies_scene, 48, 27, 2, 6, seed=15)
         write_frame(ref, "cow", S.numpy_cow_scene, 32, 18, 2, 4, seed=16)
+    if want("composite"):
+        write_intersect(ref, "cow_teapot", lambda a: cow_teapot_field_scene(ref, a, records), width=32, height=18)
+        write_frame(ref, "cow_teapot", lambda a: cow_teapot_field_scene(ref, a, records), 40, 22, 1, 4, seed=17)
+        write_smooth_normals(ref, "teapot.obj", 18)
+        write_smooth_normals(ref, "cow.obj", 23)
 
 
 if __name__ == "__main__":

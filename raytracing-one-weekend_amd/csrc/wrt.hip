@@ -463,6 +463,22 @@ __global__ void k_finalize(const float* __restrict__ accum, long long n, float s
     if (i < n) image[i] = sqrtf(accum[i] / spp);
 }
 
+// generate_image_from_data (main.py:45-74): int(255 * v) per channel, a float32 product truncated
+// towards zero, clipped to a byte as PIL does for an RGB fill; image row 0 is the top row, pixel
+// data has y = 0 at the bottom.  NaN (the reference raises on it) is stored as 0.
+__global__ void k_image_bytes(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)width * height) return;
+    const int row = (int)(i / width), column = (int)(i % width);
+    const float* px = image + ((long long)column * height + (height - 1 - row)) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float scaled = 255.0f * px[c];
+        int q = scaled != scaled ? 0 : (scaled >= 255.0f ? 255 : (scaled <= 0.0f ? 0 : (int)scaled));
+        rgb[i * 3 + c] = (uint8_t)q;
+    }
+}
+
 __global__ void k_generate_rays(const SceneRec, int width, int height, int s_begin, int n_samples,
                                 uint32_t k0, uint32_t k1, float* __restrict__ origins, float* __restrict__ dirs) {
     SceneArg S = *kernel_arguments<SceneRec>();   // the first argument, read in place
@@ -591,6 +607,13 @@ struct wrt_ctx {
     // optional timing of the bounce kernel alone (wrt_profile_*)
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+    // recorded behind the last launch that reads the scene or uses the shared workspaces, so that a
+    // scene upload, a texture replacement or a launch on another stream can be ordered after it
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    // resident workgroups per compute unit of k_render<false> / k_render<true> (asked once)
+    int render_blocks_per_cu[2] = {1, 1};
 };
 
 static thread_local std::string g_create_error;
@@ -607,9 +630,43 @@ static int fail(wrt_ctx* ctx, int code, const std::string& msg) {
             return fail(ctx, WRT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
-static int bind(wrt_ctx* ctx) {
+// The context's device is made current for the rest of the calling function; the device the
+// caller's thread had current is put back when the function returns.
+struct DeviceScope {
+    int previous = -1;
+    ~DeviceScope() { if (previous >= 0) (void)hipSetDevice(previous); }
+};
+static int bind(wrt_ctx* ctx, DeviceScope& scope) {
     if (!ctx) return fail(nullptr, WRT_E_ARG, "null context");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int current = -1;
+    HIP_TRY(ctx, hipGetDevice(&current));
+    if (current != ctx->device) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        scope.previous = current;
+    }
+    return WRT_OK;
+}
+#define WRT_BIND(ctx)            \
+    DeviceScope device_scope_;   \
+    if (int r_ = bind(ctx, device_scope_)) return r_
+
+// Launches read the scene blob, the textures and the shared workspaces asynchronously.
+// mark_use: called after the launches of an entry point on `st`.  wait_for_use: host-side wait
+// before any of those is overwritten or freed.  order_after_use: a launch on another stream than
+// the last one waits for it on the device.
+static int mark_use(wrt_ctx* ctx, hipStream_t st) {
+    HIP_TRY(ctx, hipEventRecord(ctx->last_use, st));
+    ctx->last_stream = st;
+    ctx->used = true;
+    return WRT_OK;
+}
+static int wait_for_use(wrt_ctx* ctx) {
+    if (ctx->used) HIP_TRY(ctx, hipEventSynchronize(ctx->last_use));
+    ctx->used = false;
+    return WRT_OK;
+}
+static int order_after_use(wrt_ctx* ctx, hipStream_t st) {
+    if (ctx->used && st != ctx->last_stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_use, 0));
     return WRT_OK;
 }
 
@@ -660,6 +717,20 @@ int wrt_create(int device, wrt_ctx** out) {
         delete ctx;
         return fail(nullptr, WRT_E_HIP, std::string("stats alloc: ") + hipGetErrorString(e));
     }
+    if ((e = hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming)) != hipSuccess) {
+        (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_next_batch);
+        delete ctx;
+        return fail(nullptr, WRT_E_HIP, std::string("event: ") + hipGetErrorString(e));
+    }
+    // persistent grid of the bounce kernel: as many workgroups as stay resident
+    void (*const kernels[2])(const RenderLaunch) = {k_render<false>, k_render<true>};
+    for (int k = 0; k < 2; ++k) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernels[k], RENDER_BLOCK, 0) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 1;
+        ctx->render_blocks_per_cu[k] = per_cu;
+    }
     std::memset(ctx->h_textures, 0, sizeof(ctx->h_textures));
     reset_scene(ctx);
     *out = ctx;
@@ -668,7 +739,10 @@ int wrt_create(int device, wrt_ctx** out) {
 
 int wrt_destroy(wrt_ctx* ctx) {
     if (!ctx) return WRT_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope scope;
+    (void)bind(ctx, scope);
+    if (ctx->used) (void)hipEventSynchronize(ctx->last_use);   // nothing in flight may still read what is freed below
+    if (ctx->last_use) (void)hipEventDestroy(ctx->last_use);
     for (float*& t : ctx->d_textures) if (t) { (void)hipFree(t); t = nullptr; }
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
@@ -684,7 +758,7 @@ const char* wrt_last_error(const wrt_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int wrt_device_cus(const wrt_ctx* ctx) { return ctx ? ctx->cus : 0; }
 
 int wrt_scene_clear(wrt_ctx* ctx) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     // textures stay allocated until replaced or the context is destroyed
     reset_scene(ctx);
     return WRT_OK;
@@ -700,8 +774,10 @@ static int new_group(wrt_ctx* ctx, const GroupRec& g, int* group_id) {
 
 int wrt_add_sphere_group(wrt_ctx* ctx, const float* centres, const float* radii, const uint8_t* materials,
                          int count, int* group_id) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!centres || !radii || !materials || count <= 0) return fail(ctx, WRT_E_ARG, "wrt_add_sphere_group: bad argument");
+    if (ctx->h_sph.size() + (size_t)count > (size_t)WRT_MAX_SCENE_PRIMITIVES)
+        return fail(ctx, WRT_E_LIMIT, "wrt_add_sphere_group: more than WRT_MAX_SCENE_PRIMITIVES spheres in the scene");
     std::vector<float> c, rad;
     std::vector<uint8_t> m;
     if (int r = fetch(ctx, c, centres, (size_t)count * 3)) return r;
@@ -725,11 +801,17 @@ int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const
                            const float* n1, const float* n2, const float* uv0, const float* uv1, const float* uv2,
                            int count, int material_id, const float bounds_centre[3], float bounds_radius,
                            int* group_id) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!pt0 || !A || !B || !n0 || !n1 || !n2 || !uv0 || !uv1 || !uv2 || !bounds_centre || count <= 0)
         return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: bad argument");
     if (material_id < 0 || material_id >= WRT_MAX_MATERIALS)
         return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: material index must fit uint8");
+    // the loops' queue entries hold a 16-triangle block in 16 bits and pooled items a triangle in 24
+    if (count > WRT_MAX_GROUP_TRIANGLES)
+        return fail(ctx, WRT_E_LIMIT, "wrt_add_triangle_group: more than WRT_MAX_GROUP_TRIANGLES (1048576) triangles "
+                                      "in one group: split the mesh into several groups");
+    if (ctx->h_tri_bz.size() + (size_t)count > (size_t)WRT_MAX_SCENE_PRIMITIVES)
+        return fail(ctx, WRT_E_LIMIT, "wrt_add_triangle_group: more than WRT_MAX_SCENE_PRIMITIVES triangles in the scene");
     std::vector<float> v[9];
     const float* src[9] = {pt0, A, B, n0, n1, n2, uv0, uv1, uv2};
     for (int k = 0; k < 9; ++k)
@@ -757,7 +839,7 @@ int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const
 
 int wrt_add_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], const float U[3], const float V[3],
                  double radius, int material_index, int* group_id) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!centre || !normal || !U || !V || !(radius > 0.0)) return fail(ctx, WRT_E_ARG, "wrt_add_disk: bad argument");
     if (material_index < 0 || material_index >= WRT_MAX_MATERIALS)
         return fail(ctx, WRT_E_ARG, "wrt_add_disk: material index must fit uint8");
@@ -775,7 +857,7 @@ int wrt_add_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], con
 }
 
 int wrt_set_materials(wrt_ctx* ctx, const wrt_material* table, int count) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!table || count < 0 || count > WRT_MAX_MATERIALS) return fail(ctx, WRT_E_ARG, "wrt_set_materials: bad argument");
     std::memset(ctx->h_materials, 0, sizeof(ctx->h_materials));
     for (int i = 0; i < count; ++i) {
@@ -798,10 +880,11 @@ int wrt_set_materials(wrt_ctx* ctx, const wrt_material* table, int count) {
 }
 
 int wrt_set_texture(wrt_ctx* ctx, int slot, const float* rgb, int width, int height) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (slot < 0 || slot >= WRT_MAX_TEXTURES || !rgb || width <= 0 || height <= 0)
         return fail(ctx, WRT_E_ARG, "wrt_set_texture: bad argument");
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    if (int r = wait_for_use(ctx)) return r;                  // a render in flight may still sample the old image
     if (ctx->d_textures[slot]) { HIP_TRY(ctx, hipFree(ctx->d_textures[slot])); ctx->d_textures[slot] = nullptr; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_textures[slot], bytes));
     HIP_TRY(ctx, hipMemcpy(ctx->d_textures[slot], rgb, bytes, hipMemcpyDefault));
@@ -814,7 +897,7 @@ int wrt_set_texture(wrt_ctx* ctx, int slot, const float* rgb, int width, int hei
 
 int wrt_set_camera(wrt_ctx* ctx, const double pos[3], const double U[3], const double V[3],
                    const double bottom_left[3], const double horiz[3], const double vert[3], double lens_radius) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!pos || !U || !V || !bottom_left || !horiz || !vert) return fail(ctx, WRT_E_ARG, "wrt_set_camera: null vector");
     CameraRec& c = ctx->h_cam;
     ctx->committed = false;
@@ -827,7 +910,7 @@ int wrt_set_camera(wrt_ctx* ctx, const double pos[3], const double U[3], const d
 }
 
 int wrt_set_sky(wrt_ctx* ctx, const float horizon[3], const float zenith[3]) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!horizon || !zenith) return fail(ctx, WRT_E_ARG, "wrt_set_sky: null vector");
     for (int a = 0; a < 3; ++a) { ctx->scene.horizon[a] = horizon[a]; ctx->scene.zenith[a] = zenith[a]; }
     return WRT_OK;
@@ -1109,7 +1192,7 @@ static void build_trees(wrt_ctx* ctx) {
 }
 
 int wrt_scene_commit(wrt_ctx* ctx) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
         if (ctx->h_materials[i].kind == WRT_MAT_TEXTURED && !ctx->h_textures[ctx->h_materials[i].texture].rgb)
             return fail(ctx, WRT_E_STATE, "a textured material names a texture slot that was never set");
@@ -1202,6 +1285,11 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                  b_tree = up(ctx->h_tree.size() * sizeof(f32x4) + 16);
     const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs +
                          b_bounds + b_slots + b_tree;
+    // pair_base, bound_base and tree_base are int offsets in f32x4 units
+    if (ctx->h_pairs.size() > (size_t)INT32_MAX || ctx->h_bounds.size() > (size_t)INT32_MAX ||
+        ctx->h_tree.size() > (size_t)INT32_MAX)
+        return fail(ctx, WRT_E_LIMIT, "wrt_scene_commit: the scene's loop records do not fit 32-bit offsets");
+    if (int r = wait_for_use(ctx)) return r;                  // a launch in flight may still read the old blob
     if (total > ctx->blob_bytes) {
         if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
         HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
@@ -1238,20 +1326,69 @@ int wrt_scene_commit(wrt_ctx* ctx) {
 }
 
 static int need_scene(wrt_ctx* ctx, const char* who) {
-    if (int r = bind(ctx)) return r;
     if (!ctx->committed) return fail(ctx, WRT_E_STATE, std::string(who) + ": call wrt_scene_commit first");
+    return WRT_OK;
+}
+
+// The launches of one wrt_render call: `per_launch` samples of every pixel at a
+// time through the bounce kernel into `paths`, then their per-pixel sums into accum.
+static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int n_total, int per_launch,
+                           int max_bounces, float t_min, float t_max, uint64_t seed, float* accum, float* paths,
+                           unsigned long long* next_batch, bool timed, hipStream_t st) {
+    const long long n_pixels = (long long)width * height;
+    if (int r = order_after_use(ctx, st)) return r;
+    for (int s0 = 0; s0 < n_total; s0 += per_launch) {
+        const int ns = (n_total - s0 < per_launch) ? n_total - s0 : per_launch;
+        RenderArgs A;
+        A.width = width; A.height = height; A.s_begin = s_begin + s0; A.n_samples = ns; A.max_bounces = max_bounces;
+        A.t_min = t_min; A.t_max = t_max;
+        A.k0 = (uint32_t)(seed & 0xffffffffu); A.k1 = (uint32_t)(seed >> 32);
+        A.paths = paths;
+        A.stats = ctx->d_stats;
+        A.next_batch = next_batch;
+        HIP_TRY(ctx, hipMemsetAsync(next_batch, 0, sizeof(unsigned long long), st));
+        A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
+        A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
+        const bool walk = ctx->hierarchy != 0;
+        void (*const kernel)(const RenderLaunch) = walk ? k_render<true> : k_render<false>;
+        int blocks = ctx->cus * ctx->render_blocks_per_cu[walk ? 1 : 0];
+        const long long blocks_wanted = (A.n_batches + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
+        if (blocks_wanted < blocks) blocks = (int)blocks_wanted;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (timed) {
+            HIP_TRY(ctx, hipEventCreate(&ev0));
+            HIP_TRY(ctx, hipEventCreate(&ev1));
+            HIP_TRY(ctx, hipEventRecord(ev0, st));
+        }
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RENDER_BLOCK), 0, st, RenderLaunch{ctx->scene, A});
+        HIP_TRY(ctx, hipGetLastError());
+        if (timed) {
+            HIP_TRY(ctx, hipEventRecord(ev1, st));
+            ctx->timed.emplace_back(ev0, ev1);
+        }
+        const int rblocks = (int)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_reduce_paths, dim3(rblocks), dim3(256), 0, st, A.paths, accum, n_pixels, ns,
+                           max_bounces, ctx->d_stats);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return mark_use(ctx, st);
+}
+
+static int check_render_arguments(wrt_ctx* ctx, const char* who, int width, int height, int s_begin, int s_end,
+                                  int max_bounces, const float* accum) {
+    if (width <= 0 || height <= 0 || s_begin < 0 || s_end <= s_begin || !accum)
+        return fail(ctx, WRT_E_ARG, std::string(who) + ": bad size or null accum");
+    if (max_bounces < 0 || max_bounces > WRT_MAX_BOUNCES)
+        return fail(ctx, WRT_E_LIMIT, std::string(who) + ": max_bounces must be in [0, 62]");
+    if (width > 65535 * 8 || height > 65535 * 8) return fail(ctx, WRT_E_LIMIT, std::string(who) + ": image too large");
     return WRT_OK;
 }
 
 int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces, float t_min,
                float t_max, uint64_t seed, float* accum, float* path_colours, void* stream) {
+    WRT_BIND(ctx);
     if (int r = need_scene(ctx, "wrt_render")) return r;
-    if (width <= 0 || height <= 0 || s_begin < 0 || s_end <= s_begin || !accum)
-        return fail(ctx, WRT_E_ARG, "wrt_render: bad size or null accum");
-    if (max_bounces < 0 || max_bounces > WRT_MAX_BOUNCES)
-        return fail(ctx, WRT_E_LIMIT, "wrt_render: max_bounces must be in [0, 62]");
-    if (width > 65535 * 8 || height > 65535 * 8) return fail(ctx, WRT_E_LIMIT, "wrt_render: image too large");
-    hipStream_t st = (hipStream_t)stream;
+    if (int r = check_render_arguments(ctx, "wrt_render", width, height, s_begin, s_end, max_bounces, accum)) return r;
     const long long n_pixels = (long long)width * height;
     const int n_total = s_end - s_begin;
     // samples per launch: bounded by the path workspace (16 bytes per path)
@@ -1263,70 +1400,46 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
         if (per_launch > fit) per_launch = (int)fit;
         const size_t need = (size_t)n_pixels * per_launch * 16;
         if (need > ctx->paths_bytes) {
+            if (int r = wait_for_use(ctx)) return r;          // a launch in flight may still write the old workspace
             if (ctx->d_paths) { HIP_TRY(ctx, hipFree(ctx->d_paths)); ctx->d_paths = nullptr; ctx->paths_bytes = 0; }
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_paths, need));
             ctx->paths_bytes = need;
         }
     }
-    for (int s0 = 0; s0 < n_total; s0 += per_launch) {
-        const int ns = (n_total - s0 < per_launch) ? n_total - s0 : per_launch;
-        RenderArgs A;
-        A.width = width; A.height = height; A.s_begin = s_begin + s0; A.n_samples = ns; A.max_bounces = max_bounces;
-        A.t_min = t_min; A.t_max = t_max;
-        A.k0 = (uint32_t)(seed & 0xffffffffu); A.k1 = (uint32_t)(seed >> 32);
-        A.paths = path_colours ? path_colours : ctx->d_paths;
-        A.stats = ctx->d_stats;
-        A.next_batch = ctx->d_next_batch;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_next_batch, 0, sizeof(unsigned long long), st));
-        A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
-        A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
-        // persistent grid: as many workgroups as stay resident
-        int per_cu = 0;
-        void (*const kernel)(const RenderLaunch) = ctx->hierarchy != 0 ? k_render<true> : k_render<false>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RENDER_BLOCK, 0) != hipSuccess ||
-            per_cu < 1)
-            per_cu = 1;
-        long long waves_wanted = A.n_batches;
-        int blocks = ctx->cus * per_cu;
-        const long long blocks_wanted = (waves_wanted + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
-        if (blocks_wanted < blocks) blocks = (int)blocks_wanted;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        if (ctx->profiling) {
-            HIP_TRY(ctx, hipEventCreate(&ev0));
-            HIP_TRY(ctx, hipEventCreate(&ev1));
-            HIP_TRY(ctx, hipEventRecord(ev0, st));
-        }
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RENDER_BLOCK), 0, st, RenderLaunch{ctx->scene, A});
-        HIP_TRY(ctx, hipGetLastError());
-        if (ctx->profiling) {
-            HIP_TRY(ctx, hipEventRecord(ev1, st));
-            ctx->timed.emplace_back(ev0, ev1);
-        }
-        const int rblocks = (int)((n_pixels + 255) / 256 < 4096 ? (n_pixels + 255) / 256 : 4096);
-        hipLaunchKernelGGL(k_reduce_paths, dim3(rblocks), dim3(256), 0, st, A.paths, accum, n_pixels, ns,
-                           max_bounces, ctx->d_stats);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    return WRT_OK;
+    return render_launches(ctx, width, height, s_begin, n_total, per_launch, max_bounces, t_min, t_max, seed, accum,
+                           path_colours ? path_colours : ctx->d_paths, ctx->d_next_batch, ctx->profiling,
+                           (hipStream_t)stream);
 }
 
 int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total, float* image, void* stream) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!accum || !image || n_values <= 0 || spp_total <= 0) return fail(ctx, WRT_E_ARG, "wrt_finalize: bad argument");
+    if (int r = order_after_use(ctx, (hipStream_t)stream)) return r;    // accum may come from a render on another stream
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream, accum,
                        (long long)n_values, (float)spp_total, image);
     HIP_TRY(ctx, hipGetLastError());
     return WRT_OK;
 }
 
+int wrt_image_bytes(wrt_ctx* ctx, const float* image, int width, int height, uint8_t* rgb, void* stream) {
+    WRT_BIND(ctx);
+    if (!image || !rgb || width <= 0 || height <= 0) return fail(ctx, WRT_E_ARG, "wrt_image_bytes: bad argument");
+    if (int r = order_after_use(ctx, (hipStream_t)stream)) return r;
+    const long long n = (long long)width * height;
+    hipLaunchKernelGGL(k_image_bytes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, image,
+                       width, height, rgb);
+    HIP_TRY(ctx, hipGetLastError());
+    return WRT_OK;
+}
+
 int wrt_profile_enable(wrt_ctx* ctx, int on) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     ctx->profiling = on != 0;
     return WRT_OK;
 }
 
 int wrt_profile_read(wrt_ctx* ctx, double* kernel_ms, int* launches) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!kernel_ms || !launches) return fail(ctx, WRT_E_ARG, "wrt_profile_read: null output");
     double total = 0.0;
     for (auto& pr : ctx->timed) {
@@ -1344,14 +1457,14 @@ int wrt_profile_read(wrt_ctx* ctx, double* kernel_ms, int* launches) {
 }
 
 int wrt_set_triangle_reject(wrt_ctx* ctx, int on) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     ctx->triangle_reject = on ? 1 : 0;
     ctx->scene.prefilter = ctx->triangle_reject;
     return WRT_OK;
 }
 
 int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (min_triangles < 0) return fail(ctx, WRT_E_ARG, "wrt_set_hierarchy: negative triangle count");
     ctx->hierarchy = min_triangles;
     ctx->scene.hierarchy = ctx->hierarchy;
@@ -1359,13 +1472,13 @@ int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles) {
 }
 
 int wrt_stats_reset(wrt_ctx* ctx, void* stream) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(wrt_stats), (hipStream_t)stream));
     return WRT_OK;
 }
 
 int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
     if (!out) return fail(ctx, WRT_E_ARG, "wrt_stats_read: out is null");
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     unsigned long long raw[sizeof(wrt_stats) / 8];
@@ -1393,7 +1506,8 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
 
 int wrt_generate_rays(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, uint64_t seed, float* origins,
                       float* dirs, void* stream) {
-    if (int r = bind(ctx)) return r;
+    WRT_BIND(ctx);
+    if (int r = need_scene(ctx, "wrt_generate_rays")) return r;
     if (width <= 0 || height <= 0 || s_begin < 0 || s_end <= s_begin || !origins || !dirs)
         return fail(ctx, WRT_E_ARG, "wrt_generate_rays: bad argument");
     const long long n = (long long)width * height * (s_end - s_begin);
@@ -1401,12 +1515,13 @@ int wrt_generate_rays(wrt_ctx* ctx, int width, int height, int s_begin, int s_en
                        ctx->scene, width, height, s_begin, s_end - s_begin, (uint32_t)(seed & 0xffffffffu),
                        (uint32_t)(seed >> 32), origins, dirs);
     HIP_TRY(ctx, hipGetLastError());
-    return WRT_OK;
+    return mark_use(ctx, (hipStream_t)stream);
 }
 
 int wrt_intersect(wrt_ctx* ctx, int group, const float* origins, const float* dirs, int64_t n, float t_min,
                   float t_max, uint8_t* hit, float* t, float* p, float* normal, float* uv, uint8_t* material,
                   uint8_t* back, int32_t* hit_group, int32_t* prim, void* stream) {
+    WRT_BIND(ctx);
     if (int r = need_scene(ctx, "wrt_intersect")) return r;
     if (group < -1 || group >= ctx->scene.n_groups) return fail(ctx, WRT_E_ARG, "wrt_intersect: no such group");
     if (n == 0) return WRT_OK;
@@ -1415,13 +1530,14 @@ int wrt_intersect(wrt_ctx* ctx, int group, const float* origins, const float* di
     hipLaunchKernelGGL(k_intersect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
                        group, origins, dirs, (long long)n, t_min, t_max, O);
     HIP_TRY(ctx, hipGetLastError());
-    return WRT_OK;
+    return mark_use(ctx, (hipStream_t)stream);
 }
 
 int wrt_scatter(wrt_ctx* ctx, int material_index, const float* dirs, const float* points, const float* normals,
                 const float* uvs, const uint8_t* back, const int32_t* px, const int32_t* py, const int32_t* ps,
                 int bounce, uint64_t seed, int64_t n, float* out_dirs, float* out_colours, uint8_t* absorbed,
                 void* stream) {
+    WRT_BIND(ctx);
     if (int r = need_scene(ctx, "wrt_scatter")) return r;
     if (material_index < 0 || material_index >= WRT_MAX_MATERIALS ||
         ctx->h_materials[material_index].kind == WRT_MAT_NONE)
@@ -1435,7 +1551,7 @@ int wrt_scatter(wrt_ctx* ctx, int material_index, const float* dirs, const float
                        (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (long long)n, out_dirs, out_colours,
                        absorbed);
     HIP_TRY(ctx, hipGetLastError());
-    return WRT_OK;
+    return mark_use(ctx, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -67,6 +67,7 @@ SIGNATURES = {
     "wrt_scene_commit": [_vp],
     "wrt_render": [_vp, _i, _i, _i, _i, _i, _f, _f, _u64, _vp, _vp, _vp],
     "wrt_finalize": [_vp, _vp, _i64, _i, _vp, _vp],
+    "wrt_image_bytes": [_vp, _vp, _i, _i, _vp, _vp],
     "wrt_profile_enable": [_vp, _i],
     "wrt_profile_read": [_vp, ctypes.POINTER(ctypes.c_double), _ip],
     "wrt_set_triangle_reject": [_vp, _i],
@@ -315,6 +316,15 @@ class Context:
                                          self.stream()), "wrt_finalize")
         return image
 
+    def image_bytes(self, image):
+        """(W, H, 3) float32 CUDA tensor, y up -> (H, W, 3) uint8 CUDA tensor, row 0 at the top."""
+        torch = _torch()
+        width, height = int(image.shape[0]), int(image.shape[1])
+        rgb = self.empty((height, width, 3), torch.uint8)
+        self.check(self.lib.wrt_image_bytes(self.handle, _dptr(image), width, height, _dptr(rgb), self.stream()),
+                   "wrt_image_bytes")
+        return rgb
+
     def profile(self, on):
         self.check(self.lib.wrt_profile_enable(self.handle, 1 if on else 0), "wrt_profile_enable")
 
@@ -363,10 +373,38 @@ def context(device=None):
     return _contexts[device]
 
 
+def _content_token(value):
+    """A digest of everything a flat scene holds (nested dicts / lists of arrays and scalars)."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+
+    def feed(v):
+        if isinstance(v, dict):
+            for k in sorted(v, key=str):
+                h.update(str(k).encode())
+                feed(v[k])
+        elif isinstance(v, (list, tuple)):
+            h.update(b"[%d" % len(v))
+            for item in v:
+                feed(item)
+        elif v is None:
+            h.update(b"none")
+        else:
+            a = np.ascontiguousarray(v)
+            h.update(str(a.dtype).encode() + str(a.shape).encode())
+            h.update(a.tobytes())
+    feed(value)
+    return h.digest()
+
+
 def use_scene(ctx, owner, flat_fn):
-    """Upload owner's flat scene into ctx unless it is already there."""
-    token = (id(owner), getattr(owner, "_version", 0))
+    """Upload owner's flat scene into ctx unless exactly that content is already there.
+
+    The reference's objects are mutable builders (sphere_group.py:25, camera.py:13, any attribute may
+    be assigned between calls), so what decides is the content handed to the GPU, not the identity of
+    the object: a digest of the flat scene is compared with the one of the last upload."""
+    flat = flat_fn()
+    token = _content_token(flat)
     if ctx.scene_token != token:
-        ctx.upload(flat_fn())
-        ctx._scene_owner = owner           # keeps id(owner) unique while the token is live
+        ctx.upload(flat)
         ctx.scene_token = token

@@ -23,7 +23,6 @@ class Disk():
         right = numpy.cross(self.up, self.normal)
         self.U = right / numpy.linalg.norm(right)
         self.V = numpy.cross(self.normal, self.U)
-        self._version = 0
 
     def _flat(self):
         return dict(type="disk", centre=numpy.asarray(self.centre), normal=self.normal, U=self.U, V=self.V,

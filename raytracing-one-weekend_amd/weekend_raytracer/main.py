@@ -91,13 +91,25 @@ def render():
 
 def image_bytes(image):
     """(W,H,3) float image, y up -> (H,W,3) uint8, row 0 at the top, with the
-    reference's int(255 * v) quantisation (main.py:57-65)."""
-    flipped = numpy.transpose(image, (1, 0, 2))[::-1]
-    return numpy.clip((255 * flipped.astype(numpy.double)).astype(numpy.int64), 0, 255).astype(numpy.uint8)
+    reference's int(255 * v) quantisation (main.py:57-65): a float32 product,
+    truncated, clipped to a byte as PIL does with the fill tuple.  NaN (the
+    reference raises on it) becomes 0."""
+    flipped = numpy.transpose(numpy.asarray(image, dtype=numpy.single), (1, 0, 2))[::-1]
+    scaled = numpy.nan_to_num(numpy.single(255) * flipped, nan=0.0, posinf=255.0, neginf=0.0)
+    return numpy.clip(scaled, 0, 255).astype(numpy.int64).astype(numpy.uint8)
+
+
+def image_bytes_on_device(image, device=None):
+    """The same bytes made by the GPU (wrt_image_bytes); image: (W,H,3) numpy array or CUDA tensor."""
+    import torch
+    ctx = _native.context(device)
+    if not isinstance(image, torch.Tensor):
+        image = ctx.to_device(image, numpy.single)
+    return ctx.image_bytes(image).cpu().numpy()
 
 
 def generate_image_from_data(img_data, path="tmp_image.png", show=False):
-    """Write the pixel dictionary to disk (reference main.py:45-74)."""
+    """Write the pixel dictionary to disk (reference main.py:45-74); pixels absent from it are white."""
     from PIL import Image
     image = numpy.ones((IMG_WIDTH, IMG_HEIGHT, 3), dtype=numpy.single)
     for (x, y), rgb in img_data.items():

@@ -42,8 +42,6 @@ def _scatter(material, hit_raydirs, hit_points, hit_normals, hit_uvs, hit_backfa
 
 
 class _Material():
-    _version = 0
-
     def scatter(self, hit_raydirs, hit_points, hit_normals, hit_uvs, hit_backfaces):
         """-> (new ray origins = hit_points, new directions float32 (n,3),
         colours float32 (n,3), absorbed bool (n,))."""

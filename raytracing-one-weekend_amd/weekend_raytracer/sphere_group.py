@@ -13,7 +13,6 @@ from . import _native
 class SphereGroup():
     def __init__(self):
         self._centres, self._radii, self._colours, self._materials = [], [], [], []
-        self._version = 0
         self._cache = None
 
     def add_sphere(self, centre, radius, colour, material_index):
@@ -21,7 +20,6 @@ class SphereGroup():
         self._radii.append(numpy.single(radius))
         self._colours.append(numpy.array(colour, dtype=numpy.single))
         self._materials.append(numpy.array(material_index).astype(numpy.ubyte))
-        self._version += 1
         self._cache = None
 
     def _arrays(self):

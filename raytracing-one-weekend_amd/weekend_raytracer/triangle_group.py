@@ -20,7 +20,6 @@ class TriangleGroup():
     def __init__(self, material_id):
         self.material_id = material_id
         self._rows = {f: [] for f in _FIELDS}
-        self._version = 0
         self._cache = None
         self._bounds = None
 
@@ -35,7 +34,6 @@ class TriangleGroup():
         face /= numpy.linalg.norm(face)
         for f, v in zip(_FIELDS, (pt0, pt1, pt2, uv0, uv1, uv2, normal0, normal1, normal2, A, B, face)):
             self._rows[f].append(numpy.array(v, dtype=numpy.single))
-        self._version += 1
         self._cache = None
         self._bounds = None
 

@@ -57,3 +57,35 @@ def test_two_rank_sample_sharding_matches_single_process(tmp_path):
     whole = numpy_path.render(scene, 24, 14, s, b, int(f["seed"]))
     # identical samples, float32 additions associated differently
     assert np.allclose(a0, whole["sample_sum"], rtol=1e-6, atol=1e-6)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell: the parent starts two ranks of itself (no
+    torch.distributed.run), they meet over gloo, and rank 0's JSON line comes back through the parent."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(helpers.REPO, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"launch_check": True, "ranks_seen": 2, "n_gpus": 2}
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # strong scaling cannot split 1 sample over 2 ranks ... but without a GPU the ranks already fail at
+    # the device: either way the parent must come back non-zero and print no JSON line
+    run = subprocess.run([sys.executable, os.path.join(helpers.REPO, "bench.py"), "--gpus", "2", "--workload", "demo",
+                          "--spp", "1", "--scaling", "strong", "--no-cpu", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert run.returncode != 0
+    assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]

@@ -17,13 +17,13 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 
-def full_frame(scene_fn, w, h, s, b, seed):
+def full_frame(scene_fn, w, h, s, b, seed, hierarchy=None):
     import torch
     from weekend_raytracer import _flatten, main
     with contextlib.redirect_stdout(io.StringIO()):
         objs = scene_fn(w / h)
     flat = _flatten.flatten(*objs, main.HORIZON_COLOUR, main.SKY_COLOUR)
-    frame = main.Frame(objs)
+    frame = main.Frame(objs, hierarchy=hierarchy)
     frame.ctx.stats_reset()
     paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
     accum = frame.accumulate(w, h, 0, s, b, seed, paths=paths)
@@ -43,7 +43,7 @@ def compare_subset(flat, p, sel, w, h, s, b, seed):
     return same, segs
 
 
-def check_full_frame(flat, p, a, stats, w, h, s, b, seed, n_groups_pairs):
+def check_full_frame(flat, p, a, stats, w, h, s, b, seed, n_groups_pairs, sampled=4000):
     n = w * h * s
     # every path written exactly once, by construction of the index
     assert not np.any(p[:, 3] == -7.0)
@@ -67,7 +67,7 @@ def check_full_frame(flat, p, a, stats, w, h, s, b, seed, n_groups_pairs):
     assert np.array_equal(ref.reshape(w, h, 3), a)
     # sampled paths against the CPU oracle
     rng = np.random.default_rng(2025)
-    sel = np.sort(rng.choice(n, size=4000, replace=False))
+    sel = np.sort(rng.choice(n, size=sampled, replace=False))
     same, seg_ok = compare_subset(flat, p, sel, w, h, s, b, seed)
     assert same.all(), same.mean()
     assert seg_ok.all()
@@ -98,6 +98,20 @@ def test_bunny_scene_full_size():
     segments = int(stats["rays_per_bounce"][:b].sum())
     assert stats["cull_tests"] == segments and stats["sphere_pairs"] == segments
     assert stats["triangle_pairs"] % 644 == 0 and 0 < stats["triangle_pairs"] <= segments * 644
+
+
+@pytest.mark.parametrize("hierarchy", [False, True])
+def test_cow_teapot_field_full_size(hierarchy):
+    """The multi-GPU benchmark configuration's per-GPU workload: cow.obj + teapot.obj (12 124 triangles) + the
+    sphere field at 3840x2160 (8 of its 128 samples per pixel: the streams are keyed per sample, so any
+    sample range checks the same code), every pair examined and, apart, with the optional hierarchy."""
+    from weekend_raytracer import scenes
+    w, h, s, b, seed = 3840, 2160, 8, 10, 1234
+    flat, p, a, stats = full_frame(scenes.cow_teapot_field_scene, w, h, s, b, seed, hierarchy=hierarchy)
+    check_full_frame(flat, p, a, stats, w, h, s, b, seed, None, sampled=2000)
+    segments = int(stats["rays_per_bounce"][:b].sum())
+    assert stats["sphere_pairs"] == segments * 191 and stats["cull_tests"] == 2 * segments
+    assert 0 < stats["triangle_evaluations"] < stats["triangle_pairs"] <= segments * 12124
 
 
 @pytest.mark.parametrize("scene_name,size", [

@@ -31,6 +31,7 @@ SCENES = {
     "disks": scenes.disk_test_scene,
     "bunnies": scenes.numpy_bunnies_scene,
     "cow": scenes.numpy_cow_scene,
+    "cow_teapot": scenes.cow_teapot_field_scene,
 }
 
 
@@ -85,6 +86,24 @@ def test_scene_arrays_match_reference(name):
     same(got["sky"]["zenith"], want["sky"]["zenith"], "zenith")
 
 
+def test_every_frame_fixture_has_its_scene_builder():
+    assert sorted(SCENES) == helpers.frame_names()
+
+
+@pytest.mark.parametrize("name", ["teapot", "cow"])
+def test_smooth_normals_of_the_large_meshes(name):
+    """The adjacency-based (linear) smooth normals against the reference's per-call scan over all faces
+    (obj_tri_mesh.py:27-68) on the two large meshes, for the vertices the fixture holds."""
+    f = helpers.golden("smooth_normals_" + name)
+    mesh = OBJTriMesh()
+    with contextlib.redirect_stdout(io.StringIO()):
+        mesh.read(scenes.asset(name + ".obj"))
+    assert len(f["vertices"]) >= 190
+    for vertex, want in zip(f["vertices"], f["normals"]):
+        got = mesh.get_smooth_vertex_normal(int(vertex))
+        assert str(got.dtype) == str(f["dtype"]) and np.array_equal(got, want), int(vertex)
+
+
 def test_obj_loader_conventions(tmp_path):
     path = tmp_path / "odd.obj"
     path.write_text("\n".join([
@@ -131,3 +150,27 @@ def test_sphere_field_generator_is_reproducible():
     with contextlib.redirect_stdout(io.StringIO()):
         cam, groups, mats = scenes.cover_scene(16 / 9, a)
     assert groups[0].num_spheres == 484 and max(mats) <= 254 and cam.lens_radius == 0.05
+
+
+def test_image_bytes_follow_the_reference_quantisation(tmp_path, monkeypatch):
+    """generate_image_from_data (reference main.py:45-74): int(255 * v) per channel, a float32 product,
+    rows flipped, values outside a byte clipped as PIL does with the fill tuple, absent pixels white."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    w, h = 7, 5
+    image = rng.uniform(-0.1, 1.2, size=(w, h, 3)).astype(np.single)
+    image[0, 0] = [0.0, 1.0, np.single(1.0) / np.single(255.0) * np.single(17)]
+    got = main.image_bytes(image)
+    assert got.shape == (h, w, 3) and got.dtype == np.uint8
+    for row in range(h):
+        for column in range(w):
+            want = [min(255, max(0, int(255 * v))) for v in image[column, h - 1 - row]]
+            assert list(got[row, column]) == want
+    monkeypatch.setattr(main, "IMG_WIDTH", w)
+    monkeypatch.setattr(main, "IMG_HEIGHT", h)
+    pixels = {(x, y): image[x, y] for x in range(w) for y in range(h) if (x, y) != (2, 3)}
+    main.generate_image_from_data(pixels, path=str(tmp_path / "out.png"))
+    stored = np.asarray(Image.open(tmp_path / "out.png"))
+    want = got.copy()
+    want[h - 1 - 3, 2] = 255
+    assert np.array_equal(stored, want)
