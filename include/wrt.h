@@ -155,9 +155,10 @@ int wrt_scene_commit(wrt_ctx* ctx);
 /* ---- the hot path: main.render() bounce loop (main.py:93-220) ----------- */
 /* Traces samples [s_begin, s_end) of every pixel with keyed random streams
    (counter = pixel x, y, global sample index, purpose/bounce/attempt; key =
-   seed) and ADDS, per pixel, the sum over those samples of the product of the
-   per-bounce colours to accum[(x*height + y)*3 + c] (device pointer, float32,
-   the reference's x-major pixel order, y = 0 at the bottom).
+   seed) and ADDS to accum[(x*height + y)*3 + c] (device pointer, float32, the
+   reference's x-major pixel order, y = 0 at the bottom), one sample after the
+   other in sample order, each sample's product of the per-bounce colours:
+   consecutive calls for [a, b) and [b, c) leave the same bits as one for [a, c).
    path_colours: optional device pointer [width*height*(s_end-s_begin)][4]
    receiving (r, g, b, segments traced [+100 when the path was still alive at
    the bounce limit]) per path in ray-id order

@@ -427,9 +427,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     }
 }
 
-// Per pixel: sum the path colours over this launch's samples in sample order
-// (numpy.mean over the sample axis adds sequentially, main.py:219) and add the
-// sum to the accumulation image; histogram the segment counts.
+// Per pixel: add the path colours of this launch's samples to the accumulation
+// image one by one in sample order (numpy.mean over the sample axis adds
+// sequentially, main.py:219), so that the image does not depend on how a call's
+// samples are cut into launches; histogram the segment counts.
 __global__ __launch_bounds__(256) void k_reduce_paths(const float* __restrict__ paths, float* __restrict__ accum,
                                                       long long n_pixels, int n_samples, int max_bounces,
                                                       unsigned long long* stats) {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void k_reduce_paths(const float* __restrict__ 
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < n_pixels; pix += stride) {
         const f32x4* p = reinterpret_cast<const f32x4*>(paths) + pix * n_samples;
-        float r = 0.0f, g = 0.0f, b = 0.0f;
+        float r = accum[pix * 3 + 0], g = accum[pix * 3 + 1], b = accum[pix * 3 + 2];
         for (int s = 0; s < n_samples; ++s) {
             const f32x4 v = p[s];
             r += v.x; g += v.y; b += v.z;
@@ -448,9 +449,9 @@ __global__ __launch_bounds__(256) void k_reduce_paths(const float* __restrict__ 
             entered = entered < 0 ? 0 : (entered > max_bounces + 1 ? max_bounces + 1 : entered);
             atomicAdd(&hist[entered], 1u);
         }
-        accum[pix * 3 + 0] += r;
-        accum[pix * 3 + 1] += g;
-        accum[pix * 3 + 2] += b;
+        accum[pix * 3 + 0] = r;
+        accum[pix * 3 + 1] = g;
+        accum[pix * 3 + 2] = b;
     }
     __syncthreads();
     // stats[k] = paths that entered exactly k bounces (wrt_stats_read turns this into suffix sums)
