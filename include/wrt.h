@@ -53,7 +53,8 @@ enum {
     WRT_MAX_TEXTURES = 16,
     WRT_MAX_GROUPS = 4096,
     WRT_MAX_GROUP_TRIANGLES = 1 << 20,   /* per triangle group (split larger meshes into several groups) */
-    WRT_MAX_SCENE_PRIMITIVES = 1 << 26   /* spheres, and triangles, over all groups of a scene */
+    WRT_MAX_SCENE_PRIMITIVES = 1 << 26,  /* spheres, and triangles, over all groups of a scene */
+    WRT_STATIC_MAX_PIXELS = 4 << 20      /* width * height limit of wrt_render_static (64 MiB of path records) */
 };
 
 /* materials.py: one entry per class */
@@ -167,6 +168,20 @@ int wrt_scene_commit(wrt_ctx* ctx);
 int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces,
                float t_min, float t_max, uint64_t seed, float* accum, float* path_colours,
                void* stream);
+
+/* wrt_render for callers that cannot allocate device memory.  It has no counterpart in the
+   reference; it is for code under HIP graph capture, tight serving loops and harnesses that
+   forbid hipMalloc.  Same arguments (without path_colours), same arithmetic and the same accum
+   bit for bit, but the per-launch workspace (16 bytes per path and the batch counter) is a
+   static device array of the library: 256 + 16 * WRT_STATIC_MAX_PIXELS bytes (64 MiB) that every
+   GPU the library has a context on holds until the process ends.  The call allocates and frees
+   nothing, on the device or through any library routine; it renders as many samples per launch as
+   fit the array.  width * height > WRT_STATIC_MAX_PIXELS returns WRT_E_LIMIT.  All contexts of a
+   GPU share that GPU's array: calls that overlap on one GPU (two streams, two contexts, two
+   threads) race; calls on one stream, or ordered by the caller, do not.  Kernel timing
+   (wrt_profile_enable) does not cover this entry point. */
+int wrt_render_static(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces,
+                      float t_min, float t_max, uint64_t seed, float* accum, void* stream);
 
 /* image = sqrt(accum / spp_total)  (main.py:219-220); n_values = width*height*3 */
 int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total,

@@ -571,6 +571,14 @@ __global__ __launch_bounds__(256) void k_scatter(const SceneRec, int material_in
     absorbed[i] = sc.absorbed ? 1 : 0;
 }
 
+// Workspace of wrt_render_static, the entry point that allocates nothing: 256 bytes of counters
+// followed by the path records of one launch (16 bytes per path).  Every GPU the library runs on
+// holds its own copy at its own address until the process ends; host code reaches it only through
+// the address hipGetSymbolAddress returns for that device (wrt_ctx::static_scratch), never by name.
+static constexpr size_t STATIC_COUNTER_BYTES = 256;
+static constexpr size_t STATIC_PATH_BYTES = (size_t)WRT_STATIC_MAX_PIXELS * 16;
+static __device__ __align__(256) unsigned char scratch[STATIC_COUNTER_BYTES + STATIC_PATH_BYTES];
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -615,6 +623,8 @@ struct wrt_ctx {
     bool used = false;
     // resident workgroups per compute unit of k_render<false> / k_render<true> (asked once)
     int render_blocks_per_cu[2] = {1, 1};
+    // this device's copy of the static workspace of wrt_render_static
+    unsigned char* static_scratch = nullptr;
 };
 
 static thread_local std::string g_create_error;
@@ -718,11 +728,15 @@ int wrt_create(int device, wrt_ctx** out) {
         delete ctx;
         return fail(nullptr, WRT_E_HIP, std::string("stats alloc: ") + hipGetErrorString(e));
     }
-    if ((e = hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming)) != hipSuccess) {
+    // the static workspace of this device: the array's name stands for no device address in host code
+    void* symbol = nullptr;
+    if ((e = hipGetSymbolAddress(&symbol, HIP_SYMBOL(scratch))) != hipSuccess || !symbol ||
+        (e = hipEventCreateWithFlags(&ctx->last_use, hipEventDisableTiming)) != hipSuccess) {
         (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_next_batch);
         delete ctx;
-        return fail(nullptr, WRT_E_HIP, std::string("event: ") + hipGetErrorString(e));
+        return fail(nullptr, WRT_E_HIP, std::string("static workspace / event: ") + hipGetErrorString(e));
     }
+    ctx->static_scratch = (unsigned char*)symbol;
     // persistent grid of the bounce kernel: as many workgroups as stay resident
     void (*const kernels[2])(const RenderLaunch) = {k_render<false>, k_render<true>};
     for (int k = 0; k < 2; ++k) {
@@ -1331,7 +1345,7 @@ static int need_scene(wrt_ctx* ctx, const char* who) {
     return WRT_OK;
 }
 
-// The launches of one wrt_render call: `per_launch` samples of every pixel at a
+// The launches of one wrt_render / wrt_render_static call: `per_launch` samples of every pixel at a
 // time through the bounce kernel into `paths`, then their per-pixel sums into accum.
 static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int n_total, int per_launch,
                            int max_bounces, float t_min, float t_max, uint64_t seed, float* accum, float* paths,
@@ -1410,6 +1424,26 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
     return render_launches(ctx, width, height, s_begin, n_total, per_launch, max_bounces, t_min, t_max, seed, accum,
                            path_colours ? path_colours : ctx->d_paths, ctx->d_next_batch, ctx->profiling,
                            (hipStream_t)stream);
+}
+
+int wrt_render_static(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces, float t_min,
+                      float t_max, uint64_t seed, float* accum, void* stream) {
+    WRT_BIND(ctx);
+    if (int r = need_scene(ctx, "wrt_render_static")) return r;
+    if (int r = check_render_arguments(ctx, "wrt_render_static", width, height, s_begin, s_end, max_bounces, accum))
+        return r;
+    const long long n_pixels = (long long)width * height;
+    if (n_pixels > (long long)WRT_STATIC_MAX_PIXELS)
+        return fail(ctx, WRT_E_LIMIT, "wrt_render_static: width * height exceeds WRT_STATIC_MAX_PIXELS (" +
+                                      std::to_string((long long)WRT_STATIC_MAX_PIXELS) + "), the static workspace "
+                                      "holds one sample of that many pixels; use wrt_render");
+    const long long fit = (long long)WRT_STATIC_MAX_PIXELS / n_pixels;         // samples per launch, >= 1
+    const int n_total = s_end - s_begin;
+    const int per_launch = (long long)n_total < fit ? n_total : (int)fit;
+    unsigned char* const ws = ctx->static_scratch;              // this device's copy, by address
+    return render_launches(ctx, width, height, s_begin, n_total, per_launch, max_bounces, t_min, t_max, seed, accum,
+                           reinterpret_cast<float*>(ws + STATIC_COUNTER_BYTES),
+                           reinterpret_cast<unsigned long long*>(ws), false, (hipStream_t)stream);
 }
 
 int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total, float* image, void* stream) {

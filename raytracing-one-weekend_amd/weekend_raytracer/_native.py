@@ -18,6 +18,7 @@ MAX_BOUNCES = 62
 MAX_MATERIALS = 256
 MAX_TEXTURES = 16
 SURVIVOR_MARK = 100
+STATIC_MAX_PIXELS = 4 << 20
 
 (MAT_NONE, MAT_DIFFUSE, MAT_TEXTURED, MAT_CHECKER, MAT_NORMAL_RGB, MAT_NORMAL_DISCRETE, MAT_METAL,
  MAT_DIELECTRIC) = range(8)
@@ -66,6 +67,7 @@ SIGNATURES = {
     "wrt_set_sky": [_vp, _vp, _vp],
     "wrt_scene_commit": [_vp],
     "wrt_render": [_vp, _i, _i, _i, _i, _i, _f, _f, _u64, _vp, _vp, _vp],
+    "wrt_render_static": [_vp, _i, _i, _i, _i, _i, _f, _f, _u64, _vp, _vp],
     "wrt_finalize": [_vp, _vp, _i64, _i, _vp, _vp],
     "wrt_image_bytes": [_vp, _vp, _i, _i, _vp, _vp],
     "wrt_profile_enable": [_vp, _i],
@@ -309,6 +311,12 @@ class Context:
         tensor (width*height*(s_end-s_begin), 4)."""
         self.check(self.lib.wrt_render(self.handle, width, height, s_begin, s_end, max_bounces, t_min, t_max,
                                        int(seed), _dptr(accum), _dptr(paths), self.stream()), "wrt_render")
+
+    def render_static(self, width, height, s_begin, s_end, max_bounces, seed, accum, t_min=0.001, t_max=1000.0):
+        """render() through the entry point that allocates nothing: the library's static workspace
+        holds the path records (width * height <= STATIC_MAX_PIXELS); same accum bit for bit."""
+        self.check(self.lib.wrt_render_static(self.handle, width, height, s_begin, s_end, max_bounces, t_min, t_max,
+                                              int(seed), _dptr(accum), self.stream()), "wrt_render_static")
 
     def finalize(self, accum, spp_total):
         image = self.empty(tuple(accum.shape), accum.dtype)
