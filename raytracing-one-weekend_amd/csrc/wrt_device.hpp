@@ -1036,6 +1036,7 @@ struct HitRecord {
 
 // Hit point, shading normal, uv, facing and material of the winning
 // primitive (sphere_group.py:225-259, triangle_group.py:414-450, disk.py:65-92).
+template <bool TRIANGLES = true>
 __device__ __forceinline__ void shade_record(SceneArg S, const Closest& best, const Ray& r, HitRecord& h) {
     const float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
     const GroupRec& G = S.groups[best.group];
@@ -1050,7 +1051,7 @@ __device__ __forceinline__ void shade_record(SceneArg S, const Closest& best, co
         h.n[0] = nx; h.n[1] = ny; h.n[2] = nz;
         h.uv[0] = 0.0f; h.uv[1] = 0.0f;
         h.material = S.sph_material[best.prim];
-    } else if (G.type == GROUP_TRIANGLES) {
+    } else if (TRIANGLES && G.type == GROUP_TRIANGLES) {
         const f32x4 r0 = S.tri[2 * best.prim], r1 = S.tri[2 * best.prim + 1];
         const float Ax = r0.w, Ay = r1.x, Az = r1.y, Bx = r1.z, By = r1.w, Bz = S.tri_bz[best.prim];
         const float p0 = dy * Bz - dz * By, p1 = dz * Bx - dx * Bz, p2 = dx * By - dy * Bx;
