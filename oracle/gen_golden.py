@@ -128,12 +128,15 @@ class KeyedCameraRNG:
         assert three == 3
         x, y, s = numpy.meshgrid(numpy.arange(width), numpy.arange(height),
                                  numpy.arange(samples) + self.s_begin, indexing="ij")
+        out = numpy.zeros(size)            # the third component is never used (camera.py:131,140)
         if self.calls == 0:
-            purpose, attempt = keyed_rng.JITTER, 0
+            assert (low, high) == (0.0, 1.0)
+            out[..., 0:2] = keyed_rng.jitter(self.seed, x, y, s)
         else:
-            purpose, attempt = keyed_rng.LENS, self.calls - 1
+            assert (low, high) == (-1.0, 1.0)
+            out[..., 0:2] = keyed_rng.lens_candidate(self.seed, x, y, s, self.calls - 1)
         self.calls += 1
-        return keyed_rng.keyed_uniform3(self.seed, x, y, s, purpose, 0, attempt, low, high)
+        return out
 
 
 class ScatterContext:

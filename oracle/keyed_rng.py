@@ -12,20 +12,29 @@ main.py:23) whose consumption order depends on batch composition.  To make
 what it is used for:
 
     Philox-4x32-10( counter = (x, y, sample, slot), key = (seed_lo, seed_hi) )
-    slot = purpose | bounce << 4 | attempt << 12
+    slot = purpose | bounce << 4 | call << 12
 
 where (x, y) is the pixel, sample the global sample index of the path, bounce
 the bounce number of the scatter event, purpose one of the constants below
-and attempt the index of the rejection-sampling retry.  One Philox block
-yields four 32-bit words r0..r3; a uniform double in [0, 1) is r * 2**-32 and
+and call the number of the block inside that stream.  One Philox block
+yields four 32-bit words w0..w3; a uniform double in [0, 1) is w * 2**-32 and
 uniform(low, high) = low + (high - low) * u evaluated in float64, which is
-what numpy's Generator.uniform computes from its own u.
+what numpy's Generator.uniform computes from its own u (whose resolution is
+53 bits where this one's is 32, or 21 for the unit-sphere candidates).
 
-Purposes (words used):
-    JITTER  (r0, r1)      sub-pixel offset in [0,1)^2       camera.py:130
-    LENS    (r0, r1)      lens-disk candidate in [-1,1)^2   camera.py:138-148
-    UNITVEC (r0, r1, r2)  unit-sphere candidate in [-1,1)^3 materials.py:407-426
-    SCHLICK (r0)          reflect/refract coin in [0,1)     materials.py:331
+A rejection loop is paid for by the unluckiest of the 64 paths that share a
+GPU wavefront, so one block yields two candidates:
+
+    JITTER  call 0: (w0, w1) sub-pixel offset in [0,1)^2 (camera.py:130);
+            (w2, w3) lens-disk candidate 0 in [-1,1)^2 (camera.py:138)
+    LENS    call c: (w0, w1) lens-disk candidate 1 + 2c, (w2, w3) candidate
+            2 + 2c (camera.py:141-148)
+    UNITVEC call c: unit-sphere candidates 2c and 2c + 1 in [-1,1)^3
+            (materials.py:407-426), coordinate = -1 + v * 2**-20 with a
+            21-bit integer v: the even candidate takes the top 21 bits of
+            w0, w1, w2; the odd one the low 11 bits of each followed by 10
+            bits of w3 (bits 22.., 12.., 2..)
+    SCHLICK call 0: w0, reflect/refract coin in [0,1) (materials.py:331)
 """
 import numpy as np
 
@@ -89,18 +98,38 @@ def to_unit(words):
     return words.astype(np.float64) * (1.0 / 4294967296.0)
 
 
-def keyed_uniform3(seed, x, y, sample, purpose, bounce, attempt, low, high):
-    """(n, 3) float64 uniforms in [low, high) from words r0, r1, r2."""
-    r0, r1, r2, _ = keyed_words(seed, x, y, sample, purpose, bounce, attempt)
-    u = np.stack([to_unit(r0), to_unit(r1), to_unit(r2)], axis=-1)
-    return low + (high - low) * u
+def jitter(seed, x, y, sample):
+    """(n, 2) float64 sub-pixel offsets in [0, 1)."""
+    w0, w1, _, _ = keyed_words(seed, x, y, sample, JITTER, 0, 0)
+    return np.stack([to_unit(w0), to_unit(w1)], axis=-1)
+
+
+def lens_candidate(seed, x, y, sample, attempt):
+    """(n, 2) float64 lens-disk candidate number `attempt` in [-1, 1)^2."""
+    if attempt == 0:
+        _, _, a, b = keyed_words(seed, x, y, sample, JITTER, 0, 0)
+    else:
+        w = keyed_words(seed, x, y, sample, LENS, 0, (attempt - 1) // 2)
+        a, b = (w[0], w[1]) if (attempt - 1) % 2 == 0 else (w[2], w[3])
+    return -1.0 + 2.0 * np.stack([to_unit(a), to_unit(b)], axis=-1)
+
+
+def unit_candidate(seed, x, y, sample, bounce, attempt):
+    """(n, 3) float64 unit-sphere candidate number `attempt` in [-1, 1)^3."""
+    w = keyed_words(seed, x, y, sample, UNITVEC, bounce, attempt // 2)
+    if attempt % 2 == 0:
+        v = [w[a] >> np.uint32(11) for a in range(3)]
+    else:
+        v = [((w[a] & np.uint32(0x7FF)) << np.uint32(10)) | ((w[3] >> np.uint32(22 - 10 * a)) & np.uint32(0x3FF))
+             for a in range(3)]
+    return -1.0 + np.stack(v, axis=-1).astype(np.float64) * (1.0 / 1048576.0)
 
 
 def keyed_unit_vectors(seed, x, y, sample, bounce):
     """Keyed version of the reference's numpy_random_unit_vecs
     (materials.py:401-431): draw in the cube [-1,1)^3 as float64, cast to
     float32, accept iff 1e-5 <= |v|^2 <= 1 (float32 arithmetic), redraw only
-    the rejected entries with the next attempt number, normalise in float32.
+    the rejected entries with their next candidate, normalise in float32.
     x, y, sample are 1-D integer arrays naming the path of every entry."""
     x = np.asarray(x)
     y = np.asarray(y)
@@ -110,10 +139,7 @@ def keyed_unit_vectors(seed, x, y, sample, bounce):
     pending = np.arange(n)
     attempt = 0
     while pending.size:
-        cand = keyed_uniform3(
-            seed, x[pending], y[pending], sample[pending],
-            UNITVEC, bounce, attempt, -1.0, 1.0,
-        ).astype(np.single)
+        cand = unit_candidate(seed, x[pending], y[pending], sample[pending], bounce, attempt).astype(np.single)
         vecs[pending] = cand
         len2 = np.einsum("ij,ij->i", cand, cand)
         bad = np.logical_or(len2 > 1.0, len2 < 0.00001)

@@ -56,7 +56,7 @@ def generate_rays(cam, width, height, samples, seed, s_begin=0):
 def generate_rays_for(cam, width, height, x, y, s, seed):
     """Camera rays of the paths named by pixel (x, y) and global sample index s."""
     n = x.shape[0]
-    jitter = keyed_rng.keyed_uniform3(seed, x, y, s, keyed_rng.JITTER, 0, 0, 0.0, 1.0)
+    jitter = keyed_rng.jitter(seed, x, y, s)
     # float32 pixel index + float64 offset, stored float32; then a float32 divide
     vp_u = (x.astype(np.single).astype(np.double) + jitter[:, 0]).astype(np.single) / np.single(width)
     vp_v = (y.astype(np.single).astype(np.double) + jitter[:, 1]).astype(np.single) / np.single(height)
@@ -65,9 +65,8 @@ def generate_rays_for(cam, width, height, x, y, s, seed):
     pending = np.arange(n)
     attempt = 0
     while pending.size:
-        cand = keyed_rng.keyed_uniform3(seed, x[pending], y[pending], s[pending],
-                                        keyed_rng.LENS, 0, attempt, -1.0, 1.0)
-        cand[:, 2] = 0
+        cand = np.zeros((pending.size, 3))
+        cand[:, 0:2] = keyed_rng.lens_candidate(seed, x[pending], y[pending], s[pending], attempt)
         disk[pending] = cand
         pending = pending[np.einsum("ij,ij->i", cand, cand) > 1.0]
         attempt += 1

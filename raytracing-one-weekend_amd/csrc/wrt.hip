@@ -340,8 +340,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             for (int k = 0; k < n_slots; ++k) {
                 const int n = (int)__popcll(__ballot(((pending >> k) & 1u) != 0u));
                 const bool walked = WALK && walk_from != 0 && slots[96 + k] >= walk_from;
-                long long need = 64 - (64ll * TRIP_COST) / slots[(walked ? 64 : 32) + k];
-                need = need < 8 ? 8 : need;
+                const int need = slots[(walked ? 64 : 32) + k];
                 if (n > run_n && (n >= need || !more_cheap)) { run_n = n; run_slot = k; }
             }
             if (run_slot >= 0) {
@@ -361,12 +360,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
             const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
             const WRT_CONST f32x4* records = as_uniform(S.pairs) + ugroups[run_g].pair_base;
-            if (run_slot < 0 && more_cheap) {
-                const long long loop_cost = (long long)count * (type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
-                long long need = 64 - (64ll * TRIP_COST) / loop_cost;
-                need = need < 8 ? 8 : need;
-                if (run_n < need) break;
-            }
+            if (run_slot < 0 && more_cheap && run_n < ugroups[run_g].takers) break;
             const bool mine = run_slot >= 0 ? ((pending >> run_slot) & 1u) != 0u
                                             : (state == LANE_PARKED) && (g == run_g);
             since = WRT_CLOCK();
@@ -1291,15 +1285,24 @@ int wrt_scene_commit(wrt_ctx* ctx) {
             ctx->h_slot_group.push_back((int)i);
         }
     }
-    {   // [0, 32): group index of each slot, [32, 64): estimated wave-instructions of its loop,
+    // Lanes a large group's loop waits for while other work is left: running it for n takers wastes
+    // (64 - n) lanes of a loop of `cost` wave-instructions, waiting costs another trip through shading
+    // and refill (TRIP_COST), so n >= 64 - 64 TRIP_COST / cost, at least 8.
+    auto takers_wanted = [](long long cost) {
+        const long long need = 64 - (64ll * TRIP_COST) / std::max(cost, 1ll);
+        return (int)std::max(8ll, need);
+    };
+    for (GroupRec& g : ctx->h_groups)
+        g.takers = takers_wanted((long long)g.count * (g.type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST));
+    {   // [0, 32): group index of each slot, [32, 64): takers its loop waits for,
         // [64, 96): the same when its hierarchy is walked, [96, 128): its count if it has a hierarchy, else -1
         std::vector<int> table(128, 1);
         for (size_t k = 0; k < ctx->h_slot_group.size(); ++k) {
             const GroupRec& g = ctx->h_groups[ctx->h_slot_group[k]];
             table[k] = ctx->h_slot_group[k];
-            table[32 + k] = g.count * (g.type == GROUP_TRIANGLES ? TRIANGLE_COST : SPHERE_COST);
-            table[64 + k] = g.tree_base >= 0 ? (int)(TREE_VISIT_COST * (2.0 * std::log2((double)g.count) + 10.0))
-                                             : table[32 + k];
+            table[32 + k] = g.takers;
+            table[64 + k] = g.tree_base >= 0 ? takers_wanted((int)(TREE_VISIT_COST * (2.0 * std::log2((double)g.count) + 10.0)))
+                                             : g.takers;
             table[96 + k] = g.tree_base >= 0 ? g.count : -1;
         }
         ctx->h_slot_table = table;

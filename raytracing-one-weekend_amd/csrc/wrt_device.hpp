@@ -32,7 +32,7 @@ __device__ __forceinline__ const WRT_CONST T* as_uniform(const T* p) {
 enum { GROUP_SPHERES = 0, GROUP_TRIANGLES = 1, GROUP_DISK = 2 };
 enum { PURPOSE_JITTER = 0, PURPOSE_LENS = 1, PURPOSE_UNITVEC = 2, PURPOSE_SCHLICK = 3 };
 
-struct GroupRec {            // 112 bytes, uniform
+struct GroupRec {            // 128 bytes, uniform
     int type, first, count, material;
     int pair_base;           // first f32x4 of this group's component-interleaved pair records
     int bound_base;          // triangles: first f32x4 of the per-triangle bounding records (two triangles per 4 x f32x4)
@@ -42,6 +42,8 @@ struct GroupRec {            // 112 bytes, uniform
     float reject_eps;        // triangles: eps of the reject test, as used for the bounding records' k
     int tree_base;           // triangles: first f32x4 of the group's box hierarchy, -1 = none
     float reach2;            // triangles with a hierarchy: largest distance of any corner from c
+    int takers;              // large groups: lanes the render kernel waits for before it runs the group's loop
+    int pad[3];
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -87,8 +89,8 @@ struct SceneRec {
     int prefilter;                // 1: triangle loops reject by bounding sphere first
     const f32x4* tree;            // box hierarchies of the large triangle groups: nodes, then leaf triangles
     int hierarchy;                // n > 0: triangle groups of n or more triangles that have a hierarchy are walked through it
-    const int* slot_group;        // [0, 32): group index of each slot, [32, 64): cost estimate of its loop,
-                                  // [64, 96): cost estimate with the hierarchy, [96, 128): count if it has one, else -1
+    const int* slot_group;        // [0, 32): group index of each slot, [32, 64): takers its loop waits for,
+                                  // [64, 96): the same with the hierarchy, [96, 128): count if it has one, else -1
     int n_slots;
     float horizon[3], zenith[3];
     int n_groups;
@@ -129,26 +131,50 @@ __device__ __forceinline__ double dot64(double a0, double a1, double a2, double 
     return (a0 * b0 + a2 * b2) + a1 * b1;
 }
 
+// Candidates of the two rejection loops.  A wavefront pays for its unluckiest lane in such a loop
+// (about 6.5 rounds for the unit vector where a lane alone needs 1.9), so a round is made cheap:
+// one generator call yields two candidates.
+//
+// Unit-sphere candidate number a (a = 0, 1, ...) comes from call a / 2 of the path's UNITVEC
+// stream: three 21-bit integers v, each coordinate -1 + v * 2^-20 (exact in float32, which is what
+// the reference's float64 draw cast to float32 gives for such a value, materials.py:408).  The
+// even candidate takes the top 21 bits of w0, w1, w2; the odd one the low 11 bits of each, extended
+// by 10 bits of w3 (bits 22.., 12.., 2..).
+__device__ __forceinline__ void unit_candidates(const uint32_t w[4], float even[3], float odd[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t hi = w[a] >> 11;
+        const uint32_t lo = __builtin_amdgcn_alignbit(w[a], w[3] << (10 * a), 22) & 0x1fffffu;
+        even[a] = __builtin_fmaf((float)hi, 9.5367431640625e-07f, -1.0f);
+        odd[a] = __builtin_fmaf((float)lo, 9.5367431640625e-07f, -1.0f);
+    }
+}
+
 // numpy_random_unit_vecs (materials.py:401-431) for one path
 __device__ __forceinline__ void keyed_unit_vector(const PathKey& k, uint32_t bounce, float& vx, float& vy, float& vz) {
     uint32_t r[4];
     float x, y, z, len2;
-    uint32_t attempt = 0;
+    uint32_t call = 0;
     while (true) {
-        keyed_words(k, PURPOSE_UNITVEC, bounce, attempt, r);
-        x = (float)(-1.0 + 2.0 * unit_interval(r[0]));
-        y = (float)(-1.0 + 2.0 * unit_interval(r[1]));
-        z = (float)(-1.0 + 2.0 * unit_interval(r[2]));
+        keyed_words(k, PURPOSE_UNITVEC, bounce, call, r);
+        float even[3], odd[3];
+        unit_candidates(r, even, odd);
+        x = even[0]; y = even[1]; z = even[2];
         len2 = (x * x + y * y) + z * z;
         if (!(len2 > 1.0f || len2 < 0.00001f)) break;
-        ++attempt;
+        x = odd[0]; y = odd[1]; z = odd[2];
+        len2 = (x * x + y * y) + z * z;
+        if (!(len2 > 1.0f || len2 < 0.00001f)) break;
+        ++call;
     }
     const float len = sqrtf(len2);
     vx = x / len; vy = y / len; vz = z / len;
 }
 
 // ------------------------------------------------------------------ camera
-// Camera.get_ray_components (camera.py:108-190) for one (x, y, sample)
+// Camera.get_ray_components (camera.py:108-190) for one (x, y, sample).  The path's JITTER call
+// gives the sub-pixel offset (w0, w1) and lens-disk candidate 0 (w2, w3); candidates 1 + 2c and
+// 2 + 2c are (w0, w1) and (w2, w3) of call c of its LENS stream.
 __device__ __forceinline__ void camera_ray(const CameraRec& C, int width, int height, const PathKey& k,
                                            float o[3], float d[3]) {
     uint32_t r[4];
@@ -157,13 +183,17 @@ __device__ __forceinline__ void camera_ray(const CameraRec& C, int width, int he
     const float vv = (float)((double)(float)k.y + unit_interval(r[1])) / (float)height;
     double lx = 0.0, ly = 0.0;
     if (C.lens_radius != 0.0) {
-        uint32_t attempt = 0;
-        while (true) {
-            keyed_words(k, PURPOSE_LENS, 0, attempt, r);
+        lx = -1.0 + 2.0 * unit_interval(r[2]);
+        ly = -1.0 + 2.0 * unit_interval(r[3]);
+        uint32_t call = 0;
+        while (lx * lx + ly * ly > 1.0) {
+            keyed_words(k, PURPOSE_LENS, 0, call, r);
             lx = -1.0 + 2.0 * unit_interval(r[0]);
             ly = -1.0 + 2.0 * unit_interval(r[1]);
             if (!(lx * lx + ly * ly > 1.0)) break;
-            ++attempt;
+            lx = -1.0 + 2.0 * unit_interval(r[2]);
+            ly = -1.0 + 2.0 * unit_interval(r[3]);
+            ++call;
         }
     }
     const double offx = C.lens_radius * lx, offy = C.lens_radius * ly;
