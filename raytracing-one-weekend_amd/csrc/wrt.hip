@@ -390,8 +390,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             } else if (LARGE_SPHERES) {
                 pc.sphere += (unsigned long long)run_n * (unsigned)count;
                 pc.sphere_slots += 64ull * (unsigned)count;
+#if WRT_STAGE_SPHERES_IN_LDS
+                __shared__ f32x4 staged[RENDER_BLOCK / 64][64];
+                loop_spheres_staged(S, S.pairs + ugroups[run_g].pair_base, staged[threadIdx.x >> 6], run_g, first, count,
+                                    mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2], t_min,
+                                    sentinel, queue, best);
+#else
                 loop_spheres(S, records, run_g, first, count, mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1],
                              ugroups[run_g].c[2], t_min, sentinel, queue, best);
+#endif
                 WRT_TALLY(3, since);
             }
             if (run_slot < 0) {                       // a group gone through in scene order: its lanes walk on

@@ -511,6 +511,40 @@ __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* 
     drain_spheres(S, q, g, first, r, t_min, sentinel, best);
 }
 
+// Measurement variant (-DWRT_STAGE_SPHERES_IN_LDS=1), not the shipped path: the same loop with the
+// records staged through LDS, 32 pairs (1 KB) per wave at a time, and read back by broadcast
+// ds_read_b128 into vector registers.  Kept so that the choice of scalar loads over LDS staging can
+// be measured again on any box (tools/ab.sh).
+#ifndef WRT_STAGE_SPHERES_IN_LDS
+#define WRT_STAGE_SPHERES_IN_LDS 0
+#endif
+__device__ __forceinline__ void loop_spheres_staged(SceneArg S, const f32x4* records, f32x4* tile, int g, int first,
+                                                    int count, bool active, const Ray& r, float gx, float gy,
+                                                    float gz, float t_min, float sentinel, LaneQueue& q,
+                                                    Closest& best) {
+    const unsigned lane = threadIdx.x & 63u;
+    const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
+    const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
+    const float keep = 1.0f - (3.11e-6f * dd + 2.65e-6f);
+    const float thr = !active ? __builtin_inff() : (dd <= 4.0f ? 0.00000999999f : -__builtin_inff());
+    const float minus_oo = -(oo * keep);
+    const SphereBoundRay r2 = {{2.0f * ox, 2.0f * ox}, {2.0f * oy, 2.0f * oy}, {2.0f * oz, 2.0f * oz},
+                               {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}, {d_o, d_o}, {minus_oo, minus_oo}};
+    const int pairs = (count + 1) >> 1;
+    for (int base = 0; base < pairs; base += 32) {
+        if (2 * base + (int)lane < 2 * pairs) tile[lane] = records[2 * base + (int)lane];
+        const int n = pairs - base < 32 ? pairs - base : 32;
+        for (int j = 0; j < n; ++j) {
+            if (short_of_room(q, 2)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+            const f32x4 a = tile[2 * j], b = tile[2 * j + 1];
+            const SpherePair s = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+            sphere_step(s, 2 * (base + j), count, thr, r2, q);
+        }
+    }
+    drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+}
+
 struct TriTerms2 { f32x2 det, un, vn, tn; };
 __device__ __forceinline__ TriTerms2 triangle_terms2(const Ray2& r, const TriPair& k) {
     TriTerms2 o;
