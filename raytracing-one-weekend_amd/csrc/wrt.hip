@@ -76,7 +76,7 @@ static constexpr int TRIP_COST = WRT_TRIP_COST;          // wave-instructions of
 static constexpr int TRIANGLE_COST = WRT_TRIANGLE_COST;  // wave-instructions per primitive of the uniform loops (estimate)
 static constexpr int SPHERE_COST = WRT_SPHERE_COST;
 #ifndef WRT_TREE_VISIT_COST
-#define WRT_TREE_VISIT_COST 270
+#define WRT_TREE_VISIT_COST 60
 #endif
 static constexpr int TREE_VISIT_COST = WRT_TREE_VISIT_COST;   // wave-instructions per node or leaf a walk looks at (estimate)
 
@@ -375,8 +375,14 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                     const TreeRay w = tree_ray_setup(ray, mine, ugroups[run_g].reach2, ugroups[run_g].c[0],
                                                      ugroups[run_g].c[1], ugroups[run_g].c[2]);
                     if (__ballot(!w.usable) == 0ull) {
+#if WRT_WALK_TOGETHER
+                        walk_tree_together(S.tree + ugroups[run_g].tree_base, run_g, first, ugroups[run_g].reach2,
+                                           ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2], w, ray, mine,
+                                           t_min, t_max, queue, best, pc.triangle_exact);
+#else
                         walk_tree(S.tree + ugroups[run_g].tree_base, run_g, first, w, ray, mine, t_min, t_max, queue,
                                   best, pc.triangle_exact);
+#endif
                         walked = true;
                     }
                 }

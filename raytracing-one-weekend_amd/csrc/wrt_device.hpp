@@ -943,6 +943,9 @@ enum { TREE_DONE = -2147483647 - 1 };
 #ifndef WRT_WALK_BOTH
 #define WRT_WALK_BOTH 0
 #endif
+#ifndef WRT_WALK_TOGETHER
+#define WRT_WALK_TOGETHER 1
+#endif
 __device__ __forceinline__ void walk_tree(const f32x4* __restrict__ tree, int g, int first, const TreeRay& k,
                                           const Ray& r, bool active, float t_min, float t_max, LaneQueue& q,
                                           Closest& best, unsigned long long& evaluated) {
@@ -1011,6 +1014,143 @@ __device__ __forceinline__ void walk_tree(const f32x4* __restrict__ tree, int g,
     evaluated += looked_at;
 }
 
+// The same walk with the wavefront's lanes sharing the work.  Walks differ widely in length (a ray
+// that leaves the outermost boxes is done after a few nodes, one that skims the mesh visits a
+// hundred), and a wavefront pays for every step of its longest walk.  So a lane without work
+// (its walk is over, or its ray is not at this group at all) takes the oldest entry off the stack
+// of a lane that has one - the far child nearest the root, the largest piece of work that lane has
+// put off - together with that entry's ray, and walks it as its own.  Every hit goes to the ray
+// owner's entry of `share_best` through one 64-bit minimum (ordered t << 32 | triangle), which is
+// also where every lane working on a ray reads how far that ray still has to look; the rule for
+// equal t (lowest index inside the group, earlier group across groups) is the pooled drain's.
+// What a lane computes for a borrowed ray is what the owner would have computed, so the closest
+// hit is the same bit for bit.
+//
+// The stacks are rings of QUEUE_SLOTS entries in LDS (`top` = position of the next push, `held`
+// entries below it); a steal round pairs the i-th idle lane with the i-th lane holding entries.
+#ifndef WRT_STEAL_MIN
+#define WRT_STEAL_MIN 4
+#endif
+__device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tree, int g, int first, float reach2,
+                                                   float gx, float gy, float gz, const TreeRay& own_k, const Ray& r,
+                                                   bool active, float t_min, float t_max, LaneQueue& q,
+                                                   Closest& best, unsigned long long& evaluated) {
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned* const stacks = q.slot - lane;                    // the wave's [QUEUE_SLOTS][64] entries
+    unsigned short* const donors_by_rank = reinterpret_cast<unsigned short*>(q.share_list);   // scratch of a steal round
+    const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32) |
+                                     (best.group > g ? 0xffffffffull : 0ull);
+    q.share_best[lane] = start;
+    TreeRay k = own_k;                   // the ray this lane is walking for (its own to begin with)
+    Ray c = r;
+    unsigned owner = lane;
+    int node = active ? 0 : TREE_DONE;
+    int top = 0, held = 0;
+    unsigned looked_at = 0u;
+    for (;;) {
+        const unsigned long long inner = __ballot(node >= 0);
+        const unsigned long long leaf = __ballot(node < 0 && node != TREE_DONE);
+        if ((inner | leaf) == 0ull) break;                     // an idle lane holds no entries
+        {
+            const unsigned long long idle = ~(inner | leaf), givers = __ballot(held > 0);
+            const int pairs = (int)__popcll(idle) < (int)__popcll(givers) ? (int)__popcll(idle) : (int)__popcll(givers);
+            if (pairs >= WRT_STEAL_MIN) {
+                const int rank_give = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
+                const int rank_idle = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                const bool gives = held > 0 && rank_give < pairs;
+                const bool takes = node == TREE_DONE && rank_idle < pairs;
+                int oldest = top - held;
+                oldest += oldest < 0 ? QUEUE_SLOTS : 0;
+                if (gives) {
+                    donors_by_rank[rank_give] = (unsigned short)(lane | ((unsigned)oldest << 8));
+                    --held;
+                }
+                unsigned from = lane;
+                if (takes) {
+                    const unsigned giver = donors_by_rank[rank_idle];
+                    from = giver & 63u;
+                    node = (int)stacks[(giver >> 8) * 64u + from];
+                }
+                const unsigned whose = (unsigned)__builtin_amdgcn_ds_bpermute((int)from * 4, (int)owner);
+                if (takes) owner = whose;
+                const int owner4 = (int)owner * 4;
+                Ray b;
+                b.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
+                b.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oy)));
+                b.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oz)));
+                b.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dx)));
+                b.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dy)));
+                b.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dz)));
+                if (takes) {
+                    c = b;
+                    k = tree_ray_setup(b, true, reach2, gx, gy, gz);      // the owner's own numbers, recomputed
+                }
+                continue;
+            }
+        }
+        // lanes at a leaf wait while most of the others still go down
+        const bool go_down = inner != 0ull && WRT_WALK_DEN * __popcll(leaf) < WRT_WALK_NUM * __popcll(inner | leaf);
+        if (go_down) {
+            if (node >= 0) {
+                const f32x4* n = tree + node;
+                const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                const float upper = fminf(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)), t_max);
+                float near0, near1;
+                const bool in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
+                const bool in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
+                int c0 = (int)__float_as_uint(q3.z), c1 = (int)__float_as_uint(q3.w);
+                if (in0 && in1) {
+                    if (near1 < near0) { const int s = c0; c0 = c1; c1 = s; }
+                    q.slot[top * 64] = (unsigned)c1;
+                    top = top + 1 == QUEUE_SLOTS ? 0 : top + 1;
+                    ++held;
+                    node = c0;
+                } else if (in0) {
+                    node = c0;
+                } else if (in1) {
+                    node = c1;
+                } else if (held > 0) {
+                    top = top == 0 ? QUEUE_SLOTS - 1 : top - 1;
+                    --held;
+                    node = (int)q.slot[top * 64];
+                } else {
+                    node = TREE_DONE;
+                }
+            }
+        } else {
+            if (node < 0 && node != TREE_DONE) {
+                const int code = -1 - node;
+                const int n = (code & 7) + 1;
+                const f32x4* rec = tree + (code >> 3);
+                looked_at += (unsigned)n;
+                for (int j = 0; j < n; ++j, rec += 3) {
+                    const f32x4 a = rec[0], b = rec[1], w = rec[2];
+                    const TriTerms terms = triangle_terms(c, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, w.x);
+                    float t;
+                    if (triangle_exact(terms, t_min, t_max, t))
+                        atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
+                                                            (unsigned long long)(unsigned)(first + (int)__float_as_uint(w.y)));
+                }
+                if (held > 0) {
+                    top = top == 0 ? QUEUE_SLOTS - 1 : top - 1;
+                    --held;
+                    node = (int)q.slot[top * 64];
+                } else {
+                    node = TREE_DONE;
+                }
+            }
+        }
+    }
+    const unsigned long long won = q.share_best[lane];
+    if (active && won != start) {
+        best.t = from_ordered_bits((unsigned)(won >> 32)); best.group = g; best.prim = (int)(unsigned)won;
+    }
+    for (int off = 32; off > 0; off >>= 1) looked_at += (unsigned)__shfl_xor((int)looked_at, off);
+    evaluated += looked_at;
+}
+
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
 __device__ __forceinline__ void lane_spheres(SceneArg S, int g, int first, int count, const Ray& r,
                                              float t_min, float sentinel, Closest& best) {
@@ -1068,8 +1208,14 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
                 const TreeRay w = tree_ray_setup(r, pass, groups[g].reach2, groups[g].c[0], groups[g].c[1],
                                                  groups[g].c[2]);
                 if (__ballot(!w.usable) == 0ull) {
+#if WRT_WALK_TOGETHER
+                    walk_tree_together(S.tree + groups[g].tree_base, g, first, groups[g].reach2, groups[g].c[0],
+                                       groups[g].c[1], groups[g].c[2], w, r, pass, t_min, t_max, q, best,
+                                       pc.triangle_exact);
+#else
                     walk_tree(S.tree + groups[g].tree_base, g, first, w, r, pass, t_min, t_max, q, best,
                               pc.triangle_exact);
+#endif
                     walked = true;
                 }
             }
