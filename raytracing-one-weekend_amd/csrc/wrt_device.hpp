@@ -1051,8 +1051,9 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
         const unsigned long long inner = __ballot(node >= 0);
         const unsigned long long leaf = __ballot(node < 0 && node != TREE_DONE);
         if ((inner | leaf) == 0ull) break;                     // an idle lane holds no entries
-        {
-            const unsigned long long idle = ~(inner | leaf), givers = __ballot(held > 0);
+        const unsigned long long idle = ~(inner | leaf);
+        if ((int)__popcll(idle) >= WRT_STEAL_MIN) {
+            const unsigned long long givers = __ballot(held > 0);
             const int pairs = (int)__popcll(idle) < (int)__popcll(givers) ? (int)__popcll(idle) : (int)__popcll(givers);
             if (pairs >= WRT_STEAL_MIN) {
                 const int rank_give = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32),
@@ -1076,23 +1077,25 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
                 const unsigned whose = (unsigned)__builtin_amdgcn_ds_bpermute((int)from * 4, (int)owner);
                 if (takes) owner = whose;
                 const int owner4 = (int)owner * 4;
+                // the owner's ray and the numbers it derived from it for this group, out of its registers
                 Ray b;
-                b.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
-                b.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oy)));
-                b.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oz)));
-                b.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dx)));
-                b.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dy)));
-                b.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dz)));
-                if (takes) {
-                    c = b;
-                    k = tree_ray_setup(b, true, reach2, gx, gy, gz);      // the owner's own numbers, recomputed
-                }
+                TreeRay kb;
+#define WRT_BORROW(x) __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(x)))
+                b.ox = WRT_BORROW(r.ox); b.oy = WRT_BORROW(r.oy); b.oz = WRT_BORROW(r.oz);
+                b.dx = WRT_BORROW(r.dx); b.dy = WRT_BORROW(r.dy); b.dz = WRT_BORROW(r.dz);
+                kb.ox = WRT_BORROW(own_k.ox); kb.oy = WRT_BORROW(own_k.oy); kb.oz = WRT_BORROW(own_k.oz);
+                kb.ix = WRT_BORROW(own_k.ix); kb.iy = WRT_BORROW(own_k.iy); kb.iz = WRT_BORROW(own_k.iz);
+                kb.mx = WRT_BORROW(own_k.mx); kb.my = WRT_BORROW(own_k.my); kb.mz = WRT_BORROW(own_k.mz);
+                kb.s = WRT_BORROW(own_k.s); kb.a = WRT_BORROW(own_k.a);
+#undef WRT_BORROW
+                kb.usable = true;
+                if (takes) { c = b; k = kb; }
                 continue;
             }
         }
         // lanes at a leaf wait while most of the others still go down
         const bool go_down = inner != 0ull && WRT_WALK_DEN * __popcll(leaf) < WRT_WALK_NUM * __popcll(inner | leaf);
-        if (go_down) {
+        if (WRT_WALK_BOTH || go_down) {
             if (node >= 0) {
                 const f32x4* n = tree + node;
                 const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
@@ -1119,7 +1122,8 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
                     node = TREE_DONE;
                 }
             }
-        } else {
+        }
+        if (WRT_WALK_BOTH || !go_down) {
             if (node < 0 && node != TREE_DONE) {
                 const int code = -1 - node;
                 const int n = (code & 7) + 1;
