@@ -378,6 +378,11 @@ def main():
                 "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_VECTOR_PEAK_TFLOPS, 4),
+                # achieved / frac price the reference's dense evaluation of the same pairs (a speed figure in the
+                # reference's own flops); the share of the VALU peak the kernel's own arithmetic uses is frac_executed
+                "achieved_basis": "algorithmic flops of the reference's evaluation of these pairs",
+                "frac_executed": round(executed_flops / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)
+                if kernel_ms > 0 else 0.0,
                 "traffic": traffic,
                 "kernel": "k_render",
                 "kernel_ms_avg": round(kernel_ms / max(1, launches), 4),

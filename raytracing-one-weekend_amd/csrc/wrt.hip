@@ -737,6 +737,8 @@ int wrt_create(int device, wrt_ctx** out) {
     wrt_ctx* ctx = new wrt_ctx();
     ctx->device = device;
     hipDeviceProp_t prop;
+    DeviceScope scope;                                   // the caller's device comes back on every path out
+    if (hipGetDevice(&scope.previous) != hipSuccess) scope.previous = -1;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, WRT_E_HIP, std::string("device init: ") + hipGetErrorString(e));

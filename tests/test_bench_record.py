@@ -6,8 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_default.json")) as fh:
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_default.json"))[-1]
+    with open(os.path.join(ROOT, "profiles", newest)) as fh:
         d = json.load(fh)
+    assert d["ranks_seen"] == 1
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
