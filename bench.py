@@ -427,6 +427,10 @@ def main():
                            # optional mode, reported apart: not the reference's brute-force work
                            "bunny_hierarchy": side_measurement("bunny", args.seed, local_rank, with_cpu=False,
                                                                hierarchy=64),   # below the default threshold of 1024
+                           # optional mode on the sphere scene (484 spheres: about where walking a sphere group
+                           # starts to pay), reported apart
+                           "cover_hierarchy": side_measurement("cover", args.seed, local_rank, with_cpu=False,
+                                                               hierarchy=64),
                            # textured bunny + UV-mapped cloth at its stated size
                            "cloth": side_measurement("cloth", args.seed, local_rank, steps=2, with_cpu=False),
                            # cow + teapot + sphere field at its stated per-GPU size (3840x2160, 128 spp)

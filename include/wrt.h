@@ -103,6 +103,9 @@ typedef struct wrt_stats {
        the others were rejected by the bounding-sphere test (see wrt_set_triangle_reject)
        or never looked at by a hierarchy walk (see wrt_set_hierarchy) */
     uint64_t triangle_evaluations;
+    /* (ray, sphere) pairs a hierarchy walk of a sphere group evaluated (zero while sphere groups go
+       through the uniform loop, which looks at every pair) */
+    uint64_t sphere_evaluations;
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -202,17 +205,19 @@ int wrt_image_bytes(wrt_ctx* ctx, const float* image, int width, int height, uin
 int wrt_set_triangle_reject(wrt_ctx* ctx, int on);
 
 /* No counterpart in the reference either (its README lists a spatial structure as future
-   work).  min_triangles = 0 (default): every (ray, triangle) pair of a group that passes
-   the group's bounding-sphere cull (triangle_group.py:158-166) is examined, as the
-   reference does.  min_triangles = n > 0: groups of n or more triangles (at least 16, at
-   most 32768) are walked through a box hierarchy built by wrt_scene_commit; only the
-   triangles of the leaves a ray comes near get the evaluation of triangle_group.py:289-395.
-   The boxes are grown by a bound on that evaluation's float32 error, so the closest hit
-   (t, triangle, tie order) is the same bit for bit; the work done is not the reference's,
-   and throughput in this mode is to be reported apart from the brute-force figure.  On one
-   MI355X the walk overtakes the brute-force loops at about 1000 triangles per group.
-   Takes effect with the next render or intersect. */
-int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles);
+   work).  min_primitives = 0 (default): every (ray, primitive) pair of a group is examined (for a
+   triangle group: of a group that passes its bounding-sphere cull, triangle_group.py:158-166), as
+   the reference does.  min_primitives = n > 0: triangle groups and sphere groups of n or more
+   primitives (at least 16, at most 32768) are walked through a box hierarchy built by
+   wrt_scene_commit; only the primitives of the leaves a ray comes near get the evaluation of
+   triangle_group.py:289-395 / sphere_group.py:137-205 (up to four spheres much larger than a
+   group's median stay outside its hierarchy and are looked at by every ray).  The boxes are grown
+   by a bound on that evaluation's float32 error, so the closest hit (t, primitive, tie order) is
+   the same bit for bit; the work done is not the reference's, and throughput in this mode is to
+   be reported apart from the brute-force figure.  On one MI355X the walk overtakes the
+   brute-force loops at about 1000 triangles or 500 spheres per group.  Takes effect with the
+   next render or intersect. */
+int wrt_set_hierarchy(wrt_ctx* ctx, int min_primitives);
 
 int wrt_stats_reset(wrt_ctx* ctx, void* stream);
 /* synchronises `stream`, then copies the statistics out */

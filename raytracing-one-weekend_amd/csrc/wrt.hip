@@ -154,7 +154,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
     int bounce = 0;
     Ray ray = {0, 0, 0, 0, 0, 1};
     float cr = 1, cg = 1, cb = 1;
-    PairCounts pc = {0, 0, 0, 0, 0, 0, 0};
+    PairCounts pc = {0, 0, 0, 0, 0, 0, 0, 0};
     // slot of a path in the output, ray-id order r = (x*H + y)*S + s (main.py:102-104)
     auto out_slot = [](const WRT_CONST RenderArgs& A, const PathKey& k) {
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
@@ -396,15 +396,20 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             } else if (LARGE_SPHERES) {
                 pc.sphere += (unsigned long long)run_n * (unsigned)count;
                 pc.sphere_slots += 64ull * (unsigned)count;
+                const bool walked = WALK && WRT_WALK_TOGETHER && S.hierarchy != 0 && ugroups[run_g].tree_base >= 0 &&
+                                    count >= S.hierarchy &&
+                                    walk_spheres(S, ugroups[run_g], run_g, mine, ray, t_min, t_max, queue, best, pc.sphere_exact);
+                if (!walked) {
 #if WRT_STAGE_SPHERES_IN_LDS
-                __shared__ f32x4 staged[RENDER_BLOCK / 64][64];
-                loop_spheres_staged(S, S.pairs + ugroups[run_g].pair_base, staged[threadIdx.x >> 6], run_g, first, count,
-                                    mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2], t_min,
-                                    sentinel, queue, best);
+                    __shared__ f32x4 staged[RENDER_BLOCK / 64][64];
+                    loop_spheres_staged(S, S.pairs + ugroups[run_g].pair_base, staged[threadIdx.x >> 6], run_g, first,
+                                        count, mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2],
+                                        t_min, sentinel, queue, best);
 #else
-                loop_spheres(S, records, run_g, first, count, mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1],
-                             ugroups[run_g].c[2], t_min, sentinel, queue, best);
+                    loop_spheres(S, records, run_g, first, count, mine, ray, ugroups[run_g].c[0], ugroups[run_g].c[1],
+                                 ugroups[run_g].c[2], t_min, sentinel, queue, best);
 #endif
+                }
                 WRT_TALLY(3, since);
             }
             if (run_slot < 0) {                       // a group gone through in scene order: its lanes walk on
@@ -425,6 +430,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
         if (pc.sphere_slots) atomicAdd(&A.stats[STAT_PATHS + 5], pc.sphere_slots);
         if (pc.triangle_slots) atomicAdd(&A.stats[STAT_PATHS + 6], pc.triangle_slots);
         if (pc.triangle_exact) atomicAdd(&A.stats[STAT_PATHS + 15], pc.triangle_exact);
+        if (pc.sphere_exact) atomicAdd(&A.stats[STAT_PATHS + 16], pc.sphere_exact);
 #if WRT_TIMING
         ticks[0] = ticks[1] = WRT_CLOCK() - born;
         ticks[7] = queue.drain_ticks;
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec, int group, co
         ray.dx = dirs[i * 3]; ray.dy = dirs[i * 3 + 1]; ray.dz = dirs[i * 3 + 2];
     }
     Closest best;
-    PairCounts pc = {0, 0, 0, 0, 0, 0, 0};
+    PairCounts pc = {0, 0, 0, 0, 0, 0, 0, 0};
     const int g0 = group < 0 ? 0 : group, g1 = group < 0 ? S.n_groups : group + 1;
     __shared__ unsigned queue_slots[256 / 64][QUEUE_SLOTS][64];
     __shared__ unsigned share_list[256 / 64][SHARE_ITEMS];
@@ -1069,6 +1075,7 @@ static constexpr int TREE_MIN_TRIANGLES = 16;
 #endif
 static constexpr int TREE_LEAF = WRT_TREE_LEAF;                // triangles per leaf where the height allows it
 static constexpr int TREE_MAX_TRIANGLES = 8 << QUEUE_SLOTS;     // 8 per leaf, height QUEUE_SLOTS
+static constexpr int SPHERE_TREE_OUTLIERS = 4;
 struct TreeTriangle { double lo[3], hi[3], mid[3]; float kappa; int prim; };
 struct TreeBox { float lo[3], hi[3], kappa; };
 struct TreeNode { TreeBox box[2]; int child[2]; };
@@ -1166,11 +1173,97 @@ static int build_tree_range(std::vector<TreeTriangle>& t, int lo, int hi, int le
     return (int)at * 4;
 }
 
+// Writes a built tree's nodes to ctx->h_tree; leaf children point at records of `stride` f32x4 per
+// primitive that the caller appends right behind the nodes, in the order of `t`.
+static void emit_tree_nodes(wrt_ctx* ctx, const std::vector<TreeNode>& nodes, int stride) {
+    auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
+    const int leaves_at = (int)nodes.size() * 4;
+    for (const TreeNode& n : nodes) {
+        int child[2];
+        for (int c = 0; c < 2; ++c) {
+            child[c] = n.child[c];
+            if (child[c] < 0) {
+                const int code = -1 - child[c];
+                child[c] = -1 - ((leaves_at + stride * (code >> 3)) * 8 + (code & 7));
+            }
+        }
+        const TreeBox &a = n.box[0], &b = n.box[1];
+        ctx->h_tree.push_back(f32x4{a.lo[0], a.lo[1], a.lo[2], a.hi[0]});
+        ctx->h_tree.push_back(f32x4{a.hi[1], a.hi[2], b.lo[0], b.lo[1]});
+        ctx->h_tree.push_back(f32x4{b.lo[2], b.hi[0], b.hi[1], b.hi[2]});
+        ctx->h_tree.push_back(f32x4{a.kappa, b.kappa, as_float(child[0]), as_float(child[1])});
+    }
+}
+
+// Sphere groups (walk_tree_together<GROUP_SPHERES>): the same kind of tree over the spheres' own boxes.
+// A node's kappa is 1 / (smallest radius below it): the walk grows a box by kappa * s + a with s the
+// ray's bound on how far the squared distance of a reported hit point from a sphere's centre can be
+// from r^2 (sphere_tree_ray_setup).  That bound grows with the square of the spheres' distance from
+// the group's reference point, so a few spheres much larger than the rest (a ground sphere of radius
+// 1000 under a field of radius-0.2 spheres) stay out of the tree and are looked at by every ray on
+// its own: up to SPHERE_TREE_OUTLIERS spheres of more than 8 times the median radius.
+static void build_sphere_tree(wrt_ctx* ctx, GroupRec& g) {
+    auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
+    g.n_outliers = 0;
+    if (g.count < TREE_MIN_TRIANGLES || g.count > TREE_MAX_TRIANGLES) return;
+    std::vector<float> radii((size_t)g.count);
+    for (int j = 0; j < g.count; ++j) radii[(size_t)j] = ctx->h_sph_radius[(size_t)g.first + j];
+    std::nth_element(radii.begin(), radii.begin() + g.count / 2, radii.end());
+    const double large = 8.0 * (double)radii[(size_t)(g.count / 2)];
+    std::vector<TreeTriangle> t;
+    int outliers[SPHERE_TREE_OUTLIERS];
+    int n_outliers = 0;
+    double reach = 0.0, r_max = 0.0;
+    bool usable = true;
+    for (int j = 0; j < g.count && usable; ++j) {
+        const f32x4 sph = ctx->h_sph[(size_t)g.first + j];
+        const double r = ctx->h_sph_radius[(size_t)g.first + j];
+        if (!(r > 0.0) || !std::isfinite(r) || !std::isfinite((double)sph.x + sph.y + sph.z)) { usable = false; break; }
+        if (r > large) {
+            if (n_outliers == SPHERE_TREE_OUTLIERS) { usable = false; break; }
+            outliers[n_outliers++] = j;
+            continue;
+        }
+        TreeTriangle k;
+        double d2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double c = (double)sph[a] - (double)g.c[a];
+            // the box of the sphere of radius sqrt(float32(r * r)), which is what the evaluation uses
+            const double rr = std::sqrt((double)sph.w) * (1.0 + 1e-7);
+            k.lo[a] = c - rr; k.hi[a] = c + rr; k.mid[a] = c;
+            d2 += c * c;
+        }
+        reach = std::max(reach, std::sqrt(d2));
+        r_max = std::max(r_max, std::sqrt((double)sph.w));
+        k.kappa = std::nextafter((float)(1.0 / (std::sqrt((double)sph.w) * (1.0 - 1e-6))), INFINITY);
+        k.prim = j;
+        usable = usable && std::isfinite(k.kappa);
+        t.push_back(k);
+    }
+    if (!usable || (int)t.size() < TREE_MIN_TRIANGLES || !(reach < 1e15)) return;
+    const int n = (int)t.size();
+    const int leaf_max = n <= (TREE_LEAF << QUEUE_SLOTS) ? TREE_LEAF : 8;
+    std::vector<TreeNode> nodes;
+    TreeBox whole;
+    build_tree_range(t, 0, n, leaf_max, QUEUE_SLOTS, nodes, whole);
+    g.tree_base = (int)ctx->h_tree.size();
+    g.reach2 = std::nextafter((float)reach, INFINITY);
+    g.tree_rmax = std::nextafter((float)r_max, INFINITY);
+    g.n_outliers = n_outliers;
+    for (int i = 0; i < n_outliers; ++i) g.outlier[i] = outliers[i];
+    emit_tree_nodes(ctx, nodes, 2);
+    for (const TreeTriangle& k : t) {
+        ctx->h_tree.push_back(ctx->h_sph[(size_t)g.first + k.prim]);
+        ctx->h_tree.push_back(f32x4{as_float(k.prim), 0.0f, 0.0f, 0.0f});
+    }
+}
+
 static void build_trees(wrt_ctx* ctx) {
     ctx->h_tree.clear();
     auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
     for (GroupRec& g : ctx->h_groups) {
-        g.tree_base = -1; g.reach2 = 0.0f;
+        g.tree_base = -1; g.reach2 = 0.0f; g.tree_rmax = 0.0f; g.n_outliers = 0;
+        if (g.type == GROUP_SPHERES) { build_sphere_tree(ctx, g); continue; }
         if (g.type != GROUP_TRIANGLES || g.count < TREE_MIN_TRIANGLES || g.count > TREE_MAX_TRIANGLES) continue;
         std::vector<TreeTriangle> t((size_t)g.count);
         double reach2 = 0.0;
@@ -1205,22 +1298,7 @@ static void build_trees(wrt_ctx* ctx) {
         build_tree_range(t, 0, g.count, leaf_max, QUEUE_SLOTS, nodes, whole);
         g.tree_base = (int)ctx->h_tree.size();
         g.reach2 = std::nextafter((float)reach2, INFINITY);
-        const int leaves_at = (int)nodes.size() * 4;
-        for (const TreeNode& n : nodes) {
-            int child[2];
-            for (int c = 0; c < 2; ++c) {
-                child[c] = n.child[c];
-                if (child[c] < 0) {
-                    const int code = -1 - child[c];
-                    child[c] = -1 - ((leaves_at + 3 * (code >> 3)) * 8 + (code & 7));
-                }
-            }
-            const TreeBox &a = n.box[0], &b = n.box[1];
-            ctx->h_tree.push_back(f32x4{a.lo[0], a.lo[1], a.lo[2], a.hi[0]});
-            ctx->h_tree.push_back(f32x4{a.hi[1], a.hi[2], b.lo[0], b.lo[1]});
-            ctx->h_tree.push_back(f32x4{b.lo[2], b.hi[0], b.hi[1], b.hi[2]});
-            ctx->h_tree.push_back(f32x4{a.kappa, b.kappa, as_float(child[0]), as_float(child[1])});
-        }
+        emit_tree_nodes(ctx, nodes, 3);
         for (const TreeTriangle& k : t) {
             const size_t i = (size_t)g.first + k.prim;
             ctx->h_tree.push_back(ctx->h_tri[2 * i]);
@@ -1575,6 +1653,7 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     out->triangle_lane_slots = raw[STAT_PATHS + 6];
     for (int i = 0; i < 8; ++i) out->clock_ticks[i] = raw[STAT_PATHS + 7 + i];
     out->triangle_evaluations = raw[STAT_PATHS + 15];
+    out->sphere_evaluations = raw[STAT_PATHS + 16];
     return WRT_OK;
 }
 

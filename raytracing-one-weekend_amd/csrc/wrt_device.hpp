@@ -32,7 +32,7 @@ __device__ __forceinline__ const WRT_CONST T* as_uniform(const T* p) {
 enum { GROUP_SPHERES = 0, GROUP_TRIANGLES = 1, GROUP_DISK = 2 };
 enum { PURPOSE_JITTER = 0, PURPOSE_LENS = 1, PURPOSE_UNITVEC = 2, PURPOSE_SCHLICK = 3 };
 
-struct GroupRec {            // 128 bytes, uniform
+struct GroupRec {            // 144 bytes, uniform
     int type, first, count, material;
     int pair_base;           // first f32x4 of this group's component-interleaved pair records
     int bound_base;          // triangles: first f32x4 of the per-triangle bounding records (two triangles per 4 x f32x4)
@@ -43,7 +43,10 @@ struct GroupRec {            // 128 bytes, uniform
     int tree_base;           // triangles: first f32x4 of the group's box hierarchy, -1 = none
     float reach2;            // triangles with a hierarchy: largest distance of any corner from c
     int takers;              // large groups: lanes the render kernel waits for before it runs the group's loop
-    int pad[3];
+    float tree_rmax;         // spheres with a hierarchy: largest radius in the tree
+    int n_outliers;          // spheres with a hierarchy: spheres kept out of the tree (much larger than the rest)
+    int pad;
+    int outlier[4];          // their indices inside the group
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
     float n[4];              // disk: unit normal
     float u[4];              // disk: U / radius
@@ -231,7 +234,7 @@ __device__ __forceinline__ bool closer(float t, int g, const Closest& best) {
 }
 
 // What the reference would have evaluated, for the roofline accounting
-struct PairCounts { unsigned long long sphere, triangle, cull, disk, sphere_slots, triangle_slots, triangle_exact; };
+struct PairCounts { unsigned long long sphere, triangle, cull, disk, sphere_slots, triangle_slots, triangle_exact, sphere_exact; };
 
 // ---- one (ray, primitive) pair, exactly as the reference evaluates it ------
 // sphere_group.py:137-205.  `s` = (centre, radius^2).
@@ -1014,6 +1017,51 @@ __device__ __forceinline__ void walk_tree(const f32x4* __restrict__ tree, int g,
     evaluated += looked_at;
 }
 
+// ---- the same kind of hierarchy over a sphere group ---------------------------------------------
+// A leaf holds up to 8 spheres as 2 x f32x4 each: (centre, float32(r * r)) as in S.sph, (index inside
+// the group, -, -, -); a node's kappa is 1 / (the smallest sqrt(float32(r * r)) below it), rounded up.
+// What makes the closest hit the brute-force one (sphere_group.py:137-213 evaluated in float32, round
+// to nearest, no fused operations, u = 2^-24):
+//
+// Let co_f = fl(o - c), a = |co_f|, H = d . co_f, r2 = fl(r r), |d|^2 = 1 + e with |e| <= delta, and
+// f(t) = |co_f + t d|^2 - r2 = a^2 + 2 t H + t^2 |d|^2 - r2, the squared distance of the ray's point at
+// t from the sphere, less r2.  The evaluation computes h_c = fl(d . co_f) with |h_c - H| <= 3.01u |d| a,
+// disc_c = fl(fl(h_c h_c) - fl(fl(co_f . co_f) - r2)), which differs from h_c^2 - (a^2 - r2) by
+// zeta, |zeta| <= 7.1u a^2 + 2.1u r2, then root_c = fl(sqrt(disc_c)) and the reported
+// t_c = fl(-h_c -+ root_c).  With tau = -h_c -+ root_c: tau^2 + 2 tau h_c = root_c^2 - h_c^2, hence
+//     f(tau) = zeta + (root_c^2 - disc_c) + 2 tau (H - h_c) + tau^2 e,
+// and with |tau| <= 2.43 a + sqrt(r2), disc_c <= 2.01 a^2 + r2:
+//     |f(tau)| <= 29u a^2 + 7.3u r2 + (11.8 a^2 + 2 r2) delta;
+// the rounding of tau to t_c moves f by at most 22.7u a^2 + 7.9u r2.  So the reported point lies
+// within (52u + 11.8 delta) a^2 / r' + (15.2u + 2 delta) r2 / r' of the sphere of radius r' = sqrt(r2)
+// around c (| |p| - r' | = |f| / (|p| + r') <= |f| / r'), and the exact o - c differs from co_f by at
+// most u a more.  With T >= a for every sphere in the tree (the ray origin's distance from the group's
+// reference point plus the tree's reach) and R >= every r', a box around a sphere of the tree grown by
+//     kappa s + a',   s = (52u + 11.8 delta) T^2 + (15.2u + 2 delta) R^2,   a' = 2u (T + R),
+// holds every point the evaluation can report for it, so t_c lies in that box's parameter interval,
+// and in those of the boxes above it (whose kappa is at least as large).  The rest is the triangle
+// walk's: intervals widened by their own roundings, equal t still enters, ties go to the lower index
+// inside the group and to the earlier group.  Rays with delta > 1e-3 (a refracted direction the
+// reference did not normalise) or outside the finite range make the wavefront use the uniform loop.
+__device__ __forceinline__ TreeRay sphere_tree_ray_setup(const Ray& r, bool active, float reach, float r_max,
+                                                         float gx, float gy, float gz) {
+    TreeRay k;
+    k.ox = r.ox - gx; k.oy = r.oy - gy; k.oz = r.oz - gz;
+    const float d_max = fmaxf(fmaxf(fabsf(r.dx), fabsf(r.dy)), fabsf(r.dz)), d_floor = 1.0e-18f * d_max;
+    const float dx = fabsf(r.dx) < d_floor ? copysignf(d_floor, r.dx) : r.dx;
+    const float dy = fabsf(r.dy) < d_floor ? copysignf(d_floor, r.dy) : r.dy;
+    const float dz = fabsf(r.dz) < d_floor ? copysignf(d_floor, r.dz) : r.dz;
+    k.ix = __builtin_amdgcn_rcpf(dx); k.iy = __builtin_amdgcn_rcpf(dy); k.iz = __builtin_amdgcn_rcpf(dz);
+    k.mx = -k.ox * k.ix; k.my = -k.oy * k.iy; k.mz = -k.oz * k.iz;
+    const float oo = (k.ox * k.ox + k.oy * k.oy) + k.oz * k.oz, dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    const float T = (sqrtf(oo) + reach) * 1.000001f;
+    const float delta = fabsf(dd - 1.0f) + 2.4e-7f;                 // dd itself carries four roundings
+    k.s = 1.00001f * ((3.1e-6f + 11.8f * delta) * (T * T) + (9.1e-7f + 2.0f * delta) * (r_max * r_max));
+    k.a = 1.2e-7f * (T + r_max) + 1.0e-30f;
+    k.usable = !active || (T <= 1.0e9f && d_max >= 1.0e-9f && delta <= 1.0e-3f);
+    return k;
+}
+
 // The same walk with the wavefront's lanes sharing the work.  Walks differ widely in length (a ray
 // that leaves the outermost boxes is done after a few nodes, one that skims the mesh visits a
 // hundred), and a wavefront pays for every step of its longest walk.  So a lane without work
@@ -1031,6 +1079,7 @@ __device__ __forceinline__ void walk_tree(const f32x4* __restrict__ tree, int g,
 #ifndef WRT_STEAL_MIN
 #define WRT_STEAL_MIN 4
 #endif
+template <int KIND = GROUP_TRIANGLES>
 __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tree, int g, int first, float reach2,
                                                    float gx, float gy, float gz, const TreeRay& own_k, const Ray& r,
                                                    bool active, float t_min, float t_max, LaneQueue& q,
@@ -1038,8 +1087,10 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
     const unsigned lane = threadIdx.x & 63u;
     unsigned* const stacks = q.slot - lane;                    // the wave's [QUEUE_SLOTS][64] entries
     unsigned short* const donors_by_rank = reinterpret_cast<unsigned short*>(q.share_list);   // scratch of a steal round
+    // equal t: an earlier group's hit stays (index field 0 cannot be undercut), a later group's goes, and a
+    // hit of this very group (a sphere group's outliers are looked at before the walk) is judged by its index
     const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32) |
-                                     (best.group > g ? 0xffffffffull : 0ull);
+                                     (best.group > g ? 0xffffffffull : (best.group == g ? (unsigned long long)(unsigned)best.prim : 0ull));
     q.share_best[lane] = start;
     TreeRay k = own_k;                   // the ray this lane is walking for (its own to begin with)
     Ray c = r;
@@ -1099,7 +1150,8 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
             if (node >= 0) {
                 const f32x4* n = tree + node;
                 const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                const float upper = fminf(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)), t_max);
+                const float upper = fminf(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)),
+                                          KIND == GROUP_SPHERES ? t_max + 1.0f : t_max);
                 float near0, near1;
                 const bool in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
                 const bool in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
@@ -1129,13 +1181,28 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
                 const int n = (code & 7) + 1;
                 const f32x4* rec = tree + (code >> 3);
                 looked_at += (unsigned)n;
-                for (int j = 0; j < n; ++j, rec += 3) {
-                    const f32x4 a = rec[0], b = rec[1], w = rec[2];
-                    const TriTerms terms = triangle_terms(c, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, w.x);
-                    float t;
-                    if (triangle_exact(terms, t_min, t_max, t))
-                        atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
-                                                            (unsigned long long)(unsigned)(first + (int)__float_as_uint(w.y)));
+                if (KIND == GROUP_SPHERES) {
+                    for (int j = 0; j < n; ++j, rec += 2) {
+                        const f32x4 sph = rec[0];
+                        float h;
+                        const float disc = sphere_discriminant(c, sph.x, sph.y, sph.z, sph.w, h);
+                        if (disc > 0.00001f) {
+                            // (a root beyond t_max but below the sentinel still lowers the group's t, as in the
+                            // reference: sphere_group.py:192-205)
+                            const float t = sphere_root(h, disc, t_min, t_max + 1.0f);
+                            atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
+                                                                    (unsigned long long)(unsigned)(first + (int)__float_as_uint(rec[1].x)));
+                        }
+                    }
+                } else {
+                    for (int j = 0; j < n; ++j, rec += 3) {
+                        const f32x4 a = rec[0], b = rec[1], w = rec[2];
+                        const TriTerms terms = triangle_terms(c, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, w.x);
+                        float t;
+                        if (triangle_exact(terms, t_min, t_max, t))
+                            atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
+                                                                (unsigned long long)(unsigned)(first + (int)__float_as_uint(w.y)));
+                    }
                 }
                 if (held > 0) {
                     top = top == 0 ? QUEUE_SLOTS - 1 : top - 1;
@@ -1153,6 +1220,32 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
     }
     for (int off = 32; off > 0; off >>= 1) looked_at += (unsigned)__shfl_xor((int)looked_at, off);
     evaluated += looked_at;
+}
+
+// A sphere group through its hierarchy: the few spheres kept out of the tree first, each lane on its
+// own (they bound how far the walk has to look), then the shared walk.  -> false (nothing done)
+// when a lane's ray is outside the range the boxes' growth is proven for.
+__device__ __forceinline__ bool walk_spheres(SceneArg S, const WRT_CONST GroupRec& G, int g, bool active, const Ray& r,
+                                             float t_min, float t_max, LaneQueue& q, Closest& best,
+                                             unsigned long long& evaluated) {
+    const TreeRay w = sphere_tree_ray_setup(r, active, G.reach2, G.tree_rmax, G.c[0], G.c[1], G.c[2]);
+    if (__ballot(!w.usable) != 0ull) return false;
+    const int first = G.first, n_out = G.n_outliers;
+    const float sentinel = t_max + 1.0f;
+    for (int i = 0; i < n_out; ++i) {
+        const int prim = first + G.outlier[i];
+        const f32x4 s = as_uniform(S.sph)[prim];
+        float h;
+        const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
+        const float t = sphere_root(h, disc, t_min, sentinel);
+        if (active && disc > 0.00001f && (closer(t, g, best) || (t == best.t && g == best.group && prim < best.prim))) {
+            best.t = t; best.group = g; best.prim = prim;
+        }
+    }
+    evaluated += (unsigned long long)__popcll(__ballot(active)) * (unsigned)n_out;
+    walk_tree_together<GROUP_SPHERES>(S.tree + G.tree_base, g, first, G.reach2, G.c[0], G.c[1], G.c[2], w, r, active,
+                                      t_min, t_max, q, best, evaluated);
+    return true;
 }
 
 // ---- the same pairs for one lane on its own (small groups, divergent code) ---
@@ -1195,8 +1288,10 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
         if (type == GROUP_SPHERES) {
             pc.sphere += (unsigned long long)n_live * (unsigned)count;
             pc.sphere_slots += 64ull * (unsigned)count;
-            loop_spheres(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, live, r, groups[g].c[0],
-                         groups[g].c[1], groups[g].c[2], t_min, sentinel, q, best);
+            if (!(WRT_WALK_TOGETHER && S.hierarchy != 0 && groups[g].tree_base >= 0 && count >= S.hierarchy &&
+                  walk_spheres(S, groups[g], g, live, r, t_min, t_max, q, best, pc.sphere_exact)))
+                loop_spheres(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, live, r, groups[g].c[0],
+                             groups[g].c[1], groups[g].c[2], t_min, sentinel, q, best);
         } else if (type == GROUP_TRIANGLES) {
             const bool pass = live && cull_pass(r, groups[g].c[0], groups[g].c[1], groups[g].c[2], groups[g].c[3]);
             const unsigned long long pass_mask = __ballot(pass);

@@ -185,3 +185,89 @@ def test_meshes_the_builder_declines():
         (p_on, st_on), (p_off, st_off) = both_ways(objs, 60, 40, 2, 6, seed=3)
         assert np.array_equal(p_on.view(np.uint32), p_off.view(np.uint32))
         assert st_on["triangle_pairs"] == st_off["triangle_pairs"]
+
+
+# ---- sphere groups ---------------------------------------------------------------------------
+@pytest.mark.parametrize("field,size", [
+    (None, (320, 180, 6, 10)),                # the shipped 187-sphere field (+ ground and three unit spheres)
+    (480, (1280, 720, 10, 10)),               # the benchmark's field at its full frame size, 10 of its 100 spp
+])
+def test_sphere_hierarchy_changes_nothing(field, size):
+    """A sphere group walked through its hierarchy (the ground sphere kept out of the tree) gives the frame
+    of the uniform loop bit for bit: depth-of-field camera, diffuse / fuzzy metal / glass spheres."""
+    from weekend_raytracer import scenes
+    w, h, s, b = size
+    with contextlib.redirect_stdout(io.StringIO()):
+        objs = scenes.cover_scene(w / h, None if field is None else scenes.sphere_field_records(field))
+    (p_on, st_on), (p_off, st_off) = both_ways(objs, w, h, s, b, seed=77)
+    assert np.array_equal(p_on.view(np.uint32), p_off.view(np.uint32))
+    assert np.array_equal(st_on["rays_per_bounce"], st_off["rays_per_bounce"])
+    assert st_on["sphere_pairs"] == st_off["sphere_pairs"] > 0
+
+
+@pytest.mark.parametrize("scale,offset", [
+    (1.0, (0.0, 0.0, 0.0)),
+    (0.01, (0.0, 0.0, 0.0)),
+    (100.0, (0.0, 0.0, 0.0)),
+    (1.0, (300.0, -200.0, 150.0)),
+    (0.05, (8000.0, -3000.0, 500.0)),
+])
+def test_sphere_hierarchy_on_scaled_scenes_matches_oracle(scale, offset):
+    """Small spheres, two huge ones (kept out of the tree), spheres inside spheres, far from the origin."""
+    from tests.test_gpu_reject import sphere_scene
+    from weekend_raytracer import main
+    scene = sphere_scene(scale, np.array(offset))
+    w, h, s, b = 60, 40, 3, 8
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    main_hierarchy = main.HIERARCHY
+    main.HIERARCHY = 16
+    try:
+        got = main.render_frame(objs, w, h, s, b, seed=12, want_paths=True)
+    finally:
+        main.HIERARCHY = main_hierarchy
+    want = numpy_path.render(scene, w, h, s, b, seed=12)
+    assert np.array_equal(got["path_colours"], want["path_colours"])
+    assert np.array_equal(got["counts"], want["counts"])
+
+
+def test_single_rays_hit_the_same_sphere():
+    """Rays grazing spheres, starting on and inside them, axis-parallel, unnormalised (within and beyond the
+    range the growth is proven for: the latter fall back), against the uniform loop, record by record."""
+    from tests.test_gpu_reject import sphere_scene
+    from weekend_raytracer import main
+    scene = sphere_scene(1.0, np.zeros(3), n=300, seed=8)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    c = scene["groups"][0]["centres"].astype(np.double)
+    r = scene["groups"][0]["radii"].astype(np.double)
+    rng = np.random.default_rng(6)
+    n = 20000
+    o = rng.uniform(-5, 5, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    pick = rng.integers(3, len(r), n)
+    tangent = np.cross(d, rng.normal(size=(n, 3)))
+    tangent /= np.linalg.norm(tangent, axis=1)[:, None]
+    kind = rng.integers(0, 6, n)
+    graze = c[pick] + tangent * (r[pick] * rng.uniform(0.999, 1.001, n))[:, None]    # lines that skim a sphere
+    o = np.where((kind == 1)[:, None], graze - 4.0 * d, o)
+    on_surface = c[pick] + tangent * r[pick][:, None]
+    o = np.where((kind == 2)[:, None], on_surface, o)
+    o = np.where((kind == 3)[:, None], c[pick] + 0.3 * tangent * r[pick][:, None], o)  # inside
+    axis = np.eye(3)[rng.integers(0, 3, n)] * rng.choice([-1.0, 1.0], n)[:, None]
+    d = np.where((kind == 4)[:, None], axis, d)
+    d = np.where((kind == 5)[:, None], d * rng.uniform(0.9990, 1.0010, n)[:, None], d)   # not unit length
+    d[:50] *= 3.0                                                                         # far from unit length
+    o, d = o.astype(np.single), d.astype(np.single)
+    res = []
+    for hierarchy in (16, 0):
+        frame = main.Frame(objs, hierarchy=hierarchy)
+        res.append(frame.ctx.intersect(-1, o, d, np.single(0.001), np.single(1000.0)))
+        frame.ctx.close()
+    on, off = res
+    assert off["hit"].mean() > 0.3
+    for key in ("hit", "group", "prim", "back", "mat"):
+        assert np.array_equal(on[key], off[key]), key
+    for key in ("t", "p", "n", "uv"):
+        assert np.array_equal(on[key].view(np.uint32), off[key].view(np.uint32)), key

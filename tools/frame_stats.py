@@ -22,6 +22,6 @@ for name in sys.argv[1:] or ["bunny"]:
     segments = int(st["rays_per_bounce"][:bounces].sum())
     print(f"{name}: paths {st['paths']} segments {segments} wave-segments {segments / 64:.0f}")
     for k in ("sphere_pairs", "triangle_pairs", "cull_tests", "disk_pairs", "sphere_lane_slots", "triangle_lane_slots",
-              "triangle_evaluations"):
+              "triangle_evaluations", "sphere_evaluations"):
         print(f"  {k:22s} {st[k]}")
     frame.ctx.close()
