@@ -416,7 +416,7 @@ def main():
                         "bit for bit)",
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:           # the host leg runs on rank 0 of a one-GPU job only
             out["cpu_baseline"] = cpu_baseline(kind, cpu_sample, bounces, args.seed)
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         if world == 1 and args.workload == "cover" and not args.no_cpu and not (args.spp or args.width or args.height):
