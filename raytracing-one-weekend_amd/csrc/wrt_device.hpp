@@ -1140,7 +1140,8 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
                 kb.s = WRT_BORROW(own_k.s); kb.a = WRT_BORROW(own_k.a);
 #undef WRT_BORROW
                 kb.usable = true;
-                if (takes) { c = b; k = kb; }
+                // (a lane that took nothing reads the ray it is walking anyway: c and k are always its owner's)
+                c = b; k = kb;
                 continue;
             }
         }
