@@ -237,3 +237,18 @@ def test_calls_leave_the_callers_device_alone():
     assert np.array_equal(accum.cpu().numpy(), again.cpu().numpy()) and accum.cpu().numpy().any()
     assert torch.cuda.current_device() == before
     ctx.close()
+
+
+def test_image_bytes_on_device_clip_and_nan():
+    """wrt_image_bytes against the host quantisation (reference main.py:57-65) on values outside [0, 1],
+    exact multiples of 1/255, NaN and infinities, on a ragged size."""
+    from weekend_raytracer import main
+    rng = np.random.default_rng(2)
+    w, h = 37, 19
+    image = rng.uniform(-0.2, 1.3, size=(w, h, 3)).astype(np.single)
+    image[1, 2] = [np.nan, np.inf, -np.inf]
+    image[3, 4] = np.arange(3, dtype=np.single) * np.single(1.0 / 255.0) * np.single(85)
+    image[5, 6] = [0.0, 1.0, np.nextafter(np.single(1.0), np.single(0.0))]
+    got = main.image_bytes_on_device(image)
+    assert got.shape == (h, w, 3) and got.dtype == np.uint8
+    assert np.array_equal(got, main.image_bytes(image))
