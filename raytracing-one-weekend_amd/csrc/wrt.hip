@@ -376,9 +376,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                                                      ugroups[run_g].c[1], ugroups[run_g].c[2]);
                     if (__ballot(!w.usable) == 0ull) {
 #if WRT_WALK_TOGETHER
-                        walk_tree_together(S.tree + ugroups[run_g].tree_base, run_g, first, ugroups[run_g].reach2,
-                                           ugroups[run_g].c[0], ugroups[run_g].c[1], ugroups[run_g].c[2], w, ray, mine,
-                                           t_min, t_max, queue, best, pc.triangle_exact);
+                        walk_tree_together(S.tree + ugroups[run_g].tree_base, ugroups[run_g].tree_leaf_shift, run_g,
+                                           first, w, ray, mine, t_min, t_max, queue, best, pc.triangle_exact);
 #else
                         walk_tree(S.tree + ugroups[run_g].tree_base, run_g, first, w, ray, mine, t_min, t_max, queue,
                                   best, pc.triangle_exact);
@@ -1076,6 +1075,9 @@ static constexpr int TREE_MIN_TRIANGLES = 16;
 static constexpr int TREE_LEAF = WRT_TREE_LEAF;                // triangles per leaf where the height allows it
 static constexpr int TREE_MAX_TRIANGLES = 8 << QUEUE_SLOTS;     // 8 per leaf, height QUEUE_SLOTS
 static constexpr int SPHERE_TREE_OUTLIERS = 4;
+// a tree has fewer than 4 f32x4 of nodes and 3 of leaf records per primitive, and the walk's pool packs a
+// leaf's code (offset * 8 + size - 1) into 26 bits beside the lane of the ray's owner
+static_assert(TREE_MAX_TRIANGLES * 7LL * 8 < (1LL << 26), "leaf codes must fit the pool's 26 bits");
 struct TreeTriangle { double lo[3], hi[3], mid[3]; float kappa; int prim; };
 struct TreeBox { float lo[3], hi[3], kappa; };
 struct TreeNode { TreeBox box[2]; int child[2]; };
@@ -1247,6 +1249,7 @@ static void build_sphere_tree(wrt_ctx* ctx, GroupRec& g) {
     TreeBox whole;
     build_tree_range(t, 0, n, leaf_max, QUEUE_SLOTS, nodes, whole);
     g.tree_base = (int)ctx->h_tree.size();
+    g.tree_leaf_shift = leaf_max <= 2 ? 1 : leaf_max <= 4 ? 2 : 3;
     g.reach2 = std::nextafter((float)reach, INFINITY);
     g.tree_rmax = std::nextafter((float)r_max, INFINITY);
     g.n_outliers = n_outliers;
@@ -1262,7 +1265,7 @@ static void build_trees(wrt_ctx* ctx) {
     ctx->h_tree.clear();
     auto as_float = [](int v) { float f; std::memcpy(&f, &v, 4); return f; };
     for (GroupRec& g : ctx->h_groups) {
-        g.tree_base = -1; g.reach2 = 0.0f; g.tree_rmax = 0.0f; g.n_outliers = 0;
+        g.tree_base = -1; g.reach2 = 0.0f; g.tree_rmax = 0.0f; g.n_outliers = 0; g.tree_leaf_shift = 0;
         if (g.type == GROUP_SPHERES) { build_sphere_tree(ctx, g); continue; }
         if (g.type != GROUP_TRIANGLES || g.count < TREE_MIN_TRIANGLES || g.count > TREE_MAX_TRIANGLES) continue;
         std::vector<TreeTriangle> t((size_t)g.count);
@@ -1297,6 +1300,7 @@ static void build_trees(wrt_ctx* ctx) {
         // count >= TREE_MIN_TRIANGLES: the root is a node
         build_tree_range(t, 0, g.count, leaf_max, QUEUE_SLOTS, nodes, whole);
         g.tree_base = (int)ctx->h_tree.size();
+        g.tree_leaf_shift = leaf_max <= 2 ? 1 : leaf_max <= 4 ? 2 : 3;
         g.reach2 = std::nextafter((float)reach2, INFINITY);
         emit_tree_nodes(ctx, nodes, 3);
         for (const TreeTriangle& k : t) {

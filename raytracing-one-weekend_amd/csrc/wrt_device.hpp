@@ -45,7 +45,7 @@ struct GroupRec {            // 144 bytes, uniform
     int takers;              // large groups: lanes the render kernel waits for before it runs the group's loop
     float tree_rmax;         // spheres with a hierarchy: largest radius in the tree
     int n_outliers;          // spheres with a hierarchy: spheres kept out of the tree (much larger than the rest)
-    int pad;
+    int tree_leaf_shift;     // groups with a hierarchy: a leaf holds up to 1 << this many primitives (2 or 3)
     int outlier[4];          // their indices inside the group
     float c[4];              // triangles: bounds centre, bounds_radius^2 | disk: centre, radius^2 | spheres: median centre
     float n[4];              // disk: unit normal
@@ -62,7 +62,7 @@ struct MaterialRec {         // per material index, gathered per lane
     float fuzz;              // float32(fuzziness): multiplies a float32 vector (materials.py:274)
     int fuzzy;               // fuzziness > 0.0001 evaluated on the Python float
     float ior;               // numpy.full(n, ior, dtype=single) (materials.py:319)
-    int pad;
+    int tree_leaf_shift;     // groups with a hierarchy: a leaf holds up to 1 << this many primitives (2 or 3)
 };
 
 struct TextureRec {
@@ -1067,48 +1067,114 @@ __device__ __forceinline__ TreeRay sphere_tree_ray_setup(const Ray& r, bool acti
 // hundred), and a wavefront pays for every step of its longest walk.  So a lane without work
 // (its walk is over, or its ray is not at this group at all) takes the oldest entry off the stack
 // of a lane that has one - the far child nearest the root, the largest piece of work that lane has
-// put off - together with that entry's ray, and walks it as its own.  Every hit goes to the ray
-// owner's entry of `share_best` through one 64-bit minimum (ordered t << 32 | triangle), which is
-// also where every lane working on a ray reads how far that ray still has to look; the rule for
-// equal t (lowest index inside the group, earlier group across groups) is the pooled drain's.
-// What a lane computes for a borrowed ray is what the owner would have computed, so the closest
-// hit is the same bit for bit.
+// put off - together with the numbers derived from that entry's ray, and walks it as its own.
+//
+// Leaves are not evaluated by the lane that meets them.  A child box that is met and is a leaf goes
+// into the wavefront's pool at once, (ray owner << 26 | leaf), so that a lane's node and its stack
+// entries are always inner nodes and every step is a step down for every busy lane; whenever the
+// pool holds what all 64 lanes can take (16 leaves of up to 4 primitives, or 8 of up to 8; not
+// waiting for all of it measured 2 to 4 % slower), the wavefront evaluates 64 lanes' worth of
+// pooled leaves at once, lane i the (i mod 4)-th primitive of the (i / 4)-th leaf for the ray of that
+// leaf's owner (ds_bpermute).  Every hit goes to the ray owner's entry of `share_best` through one
+// 64-bit minimum (ordered t << 32 | primitive), which is also where every lane working on a ray reads
+// how far that ray still has to look; the rule for equal t (lowest index inside the group, earlier
+// group across groups) is the pooled drain's.  A primitive is evaluated with its ray's own numbers
+// whichever lane does it, and a later evaluation only means that boxes are judged against a bound
+// that is not yet as low as it could be, so the closest hit is the same bit for bit.
 //
 // The stacks are rings of QUEUE_SLOTS entries in LDS (`top` = position of the next push, `held`
 // entries below it); a steal round pairs the i-th idle lane with the i-th lane holding entries and
-// runs as soon as one pair can be made (waiting for 2, 4, 8 pairs, or looking every second or third
-// step only, measured 1 to 5 % slower once a round had been made cheap).
+// runs as soon as one pair can be made (two for a sphere group, whose walks are short).
 #ifndef WRT_STEAL_MIN
 #define WRT_STEAL_MIN 1
 #endif
+#ifndef WRT_STEAL_MIN_SPHERES
+#define WRT_STEAL_MIN_SPHERES 2
+#endif
+#ifndef WRT_POOL_EAGER
+#define WRT_POOL_EAGER 0
+#endif
+#ifndef WRT_POOL_EAGER_SPHERES
+#define WRT_POOL_EAGER_SPHERES 0
+#endif
+enum { POOL_FIRST = 32, POOL_ROOM = SHARE_ITEMS - POOL_FIRST };
+static_assert(POOL_ROOM >= 16 + 128, "a step adds at most 128 leaves to fewer than a round's worth");
+
+// `count` pooled leaves from pool[base], count << leaf_shift <= 64: each lane evaluates one primitive
+// of one leaf for the ray of the leaf's owner
+template <int KIND>
+__device__ __forceinline__ void pooled_leaf_round(const f32x4* __restrict__ tree, const unsigned* pool, int base,
+                                                  int count, int leaf_shift, int first, const Ray& r, float t_min,
+                                                  float t_max, LaneQueue& q) {
+    const unsigned lane = threadIdx.x & 63u;
+    const int which = (int)(lane >> leaf_shift), j = (int)lane & ((1 << leaf_shift) - 1);
+    const unsigned entry = which < count ? pool[base + which] : 0u;
+    const unsigned owner = entry >> 26;
+    const int code = (int)(entry & 0x3ffffffu);
+    const bool have = which < count && j <= (code & 7);
+    const int owner4 = (int)owner * 4;
+    Ray b;
+    b.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
+    b.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oy)));
+    b.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oz)));
+    b.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dx)));
+    b.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dy)));
+    b.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dz)));
+    if (have) {
+        const f32x4* rec = tree + ((code >> 3) + j * (KIND == GROUP_SPHERES ? 2 : 3));
+        if (KIND == GROUP_SPHERES) {
+            const f32x4 sph = rec[0];
+            float h;
+            const float disc = sphere_discriminant(b, sph.x, sph.y, sph.z, sph.w, h);
+            if (disc > 0.00001f) {
+                // (a root beyond t_max but below the sentinel still lowers the group's t, as in the
+                // reference: sphere_group.py:192-205)
+                const float t = sphere_root(h, disc, t_min, t_max + 1.0f);
+                atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
+                                                    (unsigned long long)(unsigned)(first + (int)__float_as_uint(rec[1].x)));
+            }
+        } else {
+            const f32x4 a = rec[0], e = rec[1], w = rec[2];
+            const TriTerms terms = triangle_terms(b, a.x, a.y, a.z, a.w, e.x, e.y, e.z, e.w, w.x);
+            float t;
+            if (triangle_exact(terms, t_min, t_max, t))
+                atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
+                                                    (unsigned long long)(unsigned)(first + (int)__float_as_uint(w.y)));
+        }
+    }
+}
+
 template <int KIND = GROUP_TRIANGLES>
-__device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tree, int g, int first, float reach2,
-                                                   float gx, float gy, float gz, const TreeRay& own_k, const Ray& r,
+__device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tree, int leaf_shift, int g, int first,
+                                                   const TreeRay& own_k, const Ray& r,
                                                    bool active, float t_min, float t_max, LaneQueue& q,
                                                    Closest& best, unsigned long long& evaluated) {
     const unsigned lane = threadIdx.x & 63u;
     unsigned* const stacks = q.slot - lane;                    // the wave's [QUEUE_SLOTS][64] entries
     unsigned short* const donors_by_rank = reinterpret_cast<unsigned short*>(q.share_list);   // scratch of a steal round
+    unsigned* const pool = q.share_list + POOL_FIRST;
+    constexpr int steal_min = KIND == GROUP_SPHERES ? WRT_STEAL_MIN_SPHERES : WRT_STEAL_MIN;
+    const int round_leaves = 64 >> leaf_shift;
+    const int drain_at = round_leaves >> (KIND == GROUP_SPHERES ? WRT_POOL_EAGER_SPHERES : WRT_POOL_EAGER);
     // equal t: an earlier group's hit stays (index field 0 cannot be undercut), a later group's goes, and a
     // hit of this very group (a sphere group's outliers are looked at before the walk) is judged by its index
     const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32) |
                                      (best.group > g ? 0xffffffffull : (best.group == g ? (unsigned long long)(unsigned)best.prim : 0ull));
     q.share_best[lane] = start;
-    TreeRay k = own_k;                   // the ray this lane is walking for (its own to begin with)
-    Ray c = r;
+    TreeRay k = own_k;                   // of the ray this lane is walking for (its own to begin with)
     unsigned owner = lane;
     int node = active ? 0 : TREE_DONE;
     int top = 0, held = 0;
+    int pooled = 0;                      // leaves in the pool
     unsigned looked_at = 0u;
     for (;;) {
-        const unsigned long long inner = __ballot(node >= 0);
-        const unsigned long long leaf = __ballot(node < 0 && node != TREE_DONE);
-        if ((inner | leaf) == 0ull) break;                     // an idle lane holds no entries
-        const unsigned long long idle = ~(inner | leaf);
-        if ((int)__popcll(idle) >= WRT_STEAL_MIN) {
+        const unsigned long long busy = __ballot(node != TREE_DONE);
+        if (busy == 0ull) break;                               // an idle lane holds no entries
+        const unsigned long long idle = ~busy;
+        if ((int)__popcll(idle) >= steal_min) {
             const unsigned long long givers = __ballot(held > 0);
             const int pairs = (int)__popcll(idle) < (int)__popcll(givers) ? (int)__popcll(idle) : (int)__popcll(givers);
-            if (pairs >= WRT_STEAL_MIN) {
+            if (pairs >= steal_min) {
                 const int rank_give = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32),
                                            __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
                 const int rank_idle = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32),
@@ -1130,93 +1196,77 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
                 const unsigned whose = (unsigned)__builtin_amdgcn_ds_bpermute((int)from * 4, (int)owner);
                 if (takes) owner = whose;
                 const int owner4 = (int)owner * 4;
-                // the owner's ray and the numbers it derived from it for this group, out of its registers
-                Ray b;
-                TreeRay kb;
+                // the numbers the owner derived from its ray for this group, out of its registers
+                // (a lane that took nothing reads again what it has: k is always its owner's)
 #define WRT_BORROW(x) __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(x)))
-                b.ox = WRT_BORROW(r.ox); b.oy = WRT_BORROW(r.oy); b.oz = WRT_BORROW(r.oz);
-                b.dx = WRT_BORROW(r.dx); b.dy = WRT_BORROW(r.dy); b.dz = WRT_BORROW(r.dz);
-                kb.ox = WRT_BORROW(own_k.ox); kb.oy = WRT_BORROW(own_k.oy); kb.oz = WRT_BORROW(own_k.oz);
-                kb.ix = WRT_BORROW(own_k.ix); kb.iy = WRT_BORROW(own_k.iy); kb.iz = WRT_BORROW(own_k.iz);
-                kb.mx = WRT_BORROW(own_k.mx); kb.my = WRT_BORROW(own_k.my); kb.mz = WRT_BORROW(own_k.mz);
-                kb.s = WRT_BORROW(own_k.s); kb.a = WRT_BORROW(own_k.a);
+                k.ox = WRT_BORROW(own_k.ox); k.oy = WRT_BORROW(own_k.oy); k.oz = WRT_BORROW(own_k.oz);
+                k.ix = WRT_BORROW(own_k.ix); k.iy = WRT_BORROW(own_k.iy); k.iz = WRT_BORROW(own_k.iz);
+                k.mx = WRT_BORROW(own_k.mx); k.my = WRT_BORROW(own_k.my); k.mz = WRT_BORROW(own_k.mz);
+                k.s = WRT_BORROW(own_k.s); k.a = WRT_BORROW(own_k.a);
 #undef WRT_BORROW
-                kb.usable = true;
-                // (a lane that took nothing reads the ray it is walking anyway: c and k are always its owner's)
-                c = b; k = kb;
                 continue;
             }
         }
-        // lanes at a leaf wait while most of the others still go down
-        const bool go_down = inner != 0ull && WRT_WALK_DEN * __popcll(leaf) < WRT_WALK_NUM * __popcll(inner | leaf);
-        if (WRT_WALK_BOTH || go_down) {
-            if (node >= 0) {
-                const f32x4* n = tree + node;
-                const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                const float upper = fminf(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)),
-                                          KIND == GROUP_SPHERES ? t_max + 1.0f : t_max);
-                float near0, near1;
-                const bool in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
-                const bool in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
-                int c0 = (int)__float_as_uint(q3.z), c1 = (int)__float_as_uint(q3.w);
-                if (in0 && in1) {
-                    if (near1 < near0) { const int s = c0; c0 = c1; c1 = s; }
-                    q.slot[top * 64] = (unsigned)c1;
-                    top = top + 1 == QUEUE_SLOTS ? 0 : top + 1;
-                    ++held;
-                    node = c0;
-                } else if (in0) {
-                    node = c0;
-                } else if (in1) {
-                    node = c1;
-                } else if (held > 0) {
-                    top = top == 0 ? QUEUE_SLOTS - 1 : top - 1;
-                    --held;
-                    node = (int)q.slot[top * 64];
-                } else {
-                    node = TREE_DONE;
-                }
+        // two boxes; a child that is a leaf and is met goes to the pool at once, so that a lane's
+        // node and its stack entries are always inner nodes
+        bool in0 = false, in1 = false;
+        float near0 = 0.0f, near1 = 0.0f;
+        int c0 = 0, c1 = 0;
+        if (node >= 0) {
+            const f32x4* n = tree + node;
+            const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            const float upper = fminf(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)),
+                                      KIND == GROUP_SPHERES ? t_max + 1.0f : t_max);
+            in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
+            in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
+            c0 = (int)__float_as_uint(q3.z); c1 = (int)__float_as_uint(q3.w);
+        }
+        const bool leaf0 = in0 && c0 < 0, leaf1 = in1 && c1 < 0;
+        const unsigned long long leaves0 = __ballot(leaf0), leaves1 = __ballot(leaf1);
+        if ((leaves0 | leaves1) != 0ull) {
+            if (leaf0) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(leaves0 >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((unsigned)leaves0, 0u));
+                pool[pooled + rank] = (owner << 26) | (unsigned)(-1 - c0);
+                looked_at += (unsigned)((-1 - c0) & 7) + 1u;
+            }
+            pooled += (int)__popcll(leaves0);
+            if (leaf1) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(leaves1 >> 32),
+                                      __builtin_amdgcn_mbcnt_lo((unsigned)leaves1, 0u));
+                pool[pooled + rank] = (owner << 26) | (unsigned)(-1 - c1);
+                looked_at += (unsigned)((-1 - c1) & 7) + 1u;
+            }
+            pooled += (int)__popcll(leaves1);
+        }
+        if (node >= 0) {
+            in0 = in0 && c0 >= 0; in1 = in1 && c1 >= 0;
+            if (in0 && in1) {
+                if (near1 < near0) { const int s = c0; c0 = c1; c1 = s; }
+                q.slot[top * 64] = (unsigned)c1;
+                top = top + 1 == QUEUE_SLOTS ? 0 : top + 1;
+                ++held;
+                node = c0;
+            } else if (in0) {
+                node = c0;
+            } else if (in1) {
+                node = c1;
+            } else if (held > 0) {
+                top = top == 0 ? QUEUE_SLOTS - 1 : top - 1;
+                --held;
+                node = (int)q.slot[top * 64];
+            } else {
+                node = TREE_DONE;
             }
         }
-        if (WRT_WALK_BOTH || !go_down) {
-            if (node < 0 && node != TREE_DONE) {
-                const int code = -1 - node;
-                const int n = (code & 7) + 1;
-                const f32x4* rec = tree + (code >> 3);
-                looked_at += (unsigned)n;
-                if (KIND == GROUP_SPHERES) {
-                    for (int j = 0; j < n; ++j, rec += 2) {
-                        const f32x4 sph = rec[0];
-                        float h;
-                        const float disc = sphere_discriminant(c, sph.x, sph.y, sph.z, sph.w, h);
-                        if (disc > 0.00001f) {
-                            // (a root beyond t_max but below the sentinel still lowers the group's t, as in the
-                            // reference: sphere_group.py:192-205)
-                            const float t = sphere_root(h, disc, t_min, t_max + 1.0f);
-                            atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
-                                                                    (unsigned long long)(unsigned)(first + (int)__float_as_uint(rec[1].x)));
-                        }
-                    }
-                } else {
-                    for (int j = 0; j < n; ++j, rec += 3) {
-                        const f32x4 a = rec[0], b = rec[1], w = rec[2];
-                        const TriTerms terms = triangle_terms(c, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, w.x);
-                        float t;
-                        if (triangle_exact(terms, t_min, t_max, t))
-                            atomicMin(&q.share_best[owner], ((unsigned long long)ordered_bits(t) << 32) |
-                                                                (unsigned long long)(unsigned)(first + (int)__float_as_uint(w.y)));
-                    }
-                }
-                if (held > 0) {
-                    top = top == 0 ? QUEUE_SLOTS - 1 : top - 1;
-                    --held;
-                    node = (int)q.slot[top * 64];
-                } else {
-                    node = TREE_DONE;
-                }
-            }
+        while (pooled >= drain_at) {
+            const int count = pooled < round_leaves ? pooled : round_leaves;
+            pooled -= count;
+            pooled_leaf_round<KIND>(tree, pool, pooled, count, leaf_shift, first, r, t_min, t_max, q);
         }
     }
+    // what is left in the pool
+    if (pooled > 0) pooled_leaf_round<KIND>(tree, pool, 0, pooled, leaf_shift, first, r, t_min, t_max, q);
     const unsigned long long won = q.share_best[lane];
     if (active && won != start) {
         best.t = from_ordered_bits((unsigned)(won >> 32)); best.group = g; best.prim = (int)(unsigned)won;
@@ -1246,8 +1296,8 @@ __device__ __forceinline__ bool walk_spheres(SceneArg S, const WRT_CONST GroupRe
         }
     }
     evaluated += (unsigned long long)__popcll(__ballot(active)) * (unsigned)n_out;
-    walk_tree_together<GROUP_SPHERES>(S.tree + G.tree_base, g, first, G.reach2, G.c[0], G.c[1], G.c[2], w, r, active,
-                                      t_min, t_max, q, best, evaluated);
+    walk_tree_together<GROUP_SPHERES>(S.tree + G.tree_base, G.tree_leaf_shift, g, first, w, r, active, t_min, t_max, q,
+                                      best, evaluated);
     return true;
 }
 
@@ -1311,9 +1361,8 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
                                                  groups[g].c[2]);
                 if (__ballot(!w.usable) == 0ull) {
 #if WRT_WALK_TOGETHER
-                    walk_tree_together(S.tree + groups[g].tree_base, g, first, groups[g].reach2, groups[g].c[0],
-                                       groups[g].c[1], groups[g].c[2], w, r, pass, t_min, t_max, q, best,
-                                       pc.triangle_exact);
+                    walk_tree_together(S.tree + groups[g].tree_base, groups[g].tree_leaf_shift, g, first, w, r, pass,
+                                       t_min, t_max, q, best, pc.triangle_exact);
 #else
                     walk_tree(S.tree + groups[g].tree_base, g, first, w, r, pass, t_min, t_max, q, best,
                               pc.triangle_exact);
