@@ -86,6 +86,9 @@ static constexpr int TREE_VISIT_COST = WRT_TREE_VISIT_COST;   // wave-instructio
 #ifndef WRT_WAVES_PER_SIMD
 #define WRT_WAVES_PER_SIMD 6
 #endif
+#ifndef WRT_WAVES_PER_SIMD_WALK
+#define WRT_WAVES_PER_SIMD_WALK WRT_WAVES_PER_SIMD
+#endif
 // Sum of `count` over the lanes with `take` set (each evaluated `count` pairs of
 // a small group on its own); must be called by the whole wave; wave-uniform result.
 __device__ __forceinline__ unsigned long long wave_sum_small(bool take, int count) {
@@ -121,7 +124,7 @@ __device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
 // TRIANGLES / LARGE_SPHERES: the scene has triangle groups / sphere groups large enough for the
 // wave-uniform loop; an instance without one of them carries none of its code, registers or LDS.
 template <bool WALK, bool TRIANGLES, bool LARGE_SPHERES>
-__global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
+__global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
     __shared__ float batch_rays[RENDER_BLOCK / 64][6][64];
@@ -375,13 +378,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
                     const TreeRay w = tree_ray_setup(ray, mine, ugroups[run_g].reach2, ugroups[run_g].c[0],
                                                      ugroups[run_g].c[1], ugroups[run_g].c[2]);
                     if (__ballot(!w.usable) == 0ull) {
-#if WRT_WALK_TOGETHER
                         walk_tree_together(S.tree + ugroups[run_g].tree_base, ugroups[run_g].tree_leaf_shift, run_g,
                                            first, w, ray, mine, t_min, t_max, queue, best, pc.triangle_exact);
-#else
-                        walk_tree(S.tree + ugroups[run_g].tree_base, run_g, first, w, ray, mine, t_min, t_max, queue,
-                                  best, pc.triangle_exact);
-#endif
                         walked = true;
                     }
                 }
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WRT_WAVES_PER_SIMD) void k_render(con
             } else if (LARGE_SPHERES) {
                 pc.sphere += (unsigned long long)run_n * (unsigned)count;
                 pc.sphere_slots += 64ull * (unsigned)count;
-                const bool walked = WALK && WRT_WALK_TOGETHER && S.hierarchy != 0 && ugroups[run_g].tree_base >= 0 &&
+                const bool walked = WALK && S.hierarchy != 0 && ugroups[run_g].tree_base >= 0 &&
                                     count >= S.hierarchy &&
                                     walk_spheres(S, ugroups[run_g], run_g, mine, ray, t_min, t_max, queue, best, pc.sphere_exact);
                 if (!walked) {
@@ -1064,10 +1062,10 @@ static void build_bounds(wrt_ctx* ctx) {
     for (int i = 0; i < 8; ++i) ctx->h_bounds.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
 }
 
-// Box hierarchy of each triangle group of TREE_MIN_TRIANGLES or more (walk_tree): split planes by the
+// Box hierarchy of each triangle group of TREE_MIN_TRIANGLES or more (walk_tree_together): split planes by the
 // surface-area heuristic among those that keep the height within the walk's stack (else halves by
 // count at the median centroid along the widest axis);
-// boxes relative to the group's bounds centre, rounded outwards; kappa as walk_tree's comment derives it.
+// boxes relative to the group's bounds centre, rounded outwards; kappa as the comment above tree_ray_setup derives it.
 static constexpr int TREE_MIN_TRIANGLES = 16;
 #ifndef WRT_TREE_LEAF
 #define WRT_TREE_LEAF 4

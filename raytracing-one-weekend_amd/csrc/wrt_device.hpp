@@ -939,83 +939,6 @@ __device__ __forceinline__ bool tree_box(const TreeRay& k, float lox, float loy,
 // (P0, A.x) (A.yz, B.xy) (B.z, index inside the group, -, -), the numbers of S.tri / S.tri_bz.
 // The lane's stack lives in its queue slots (QUEUE_SLOTS entries: the builder keeps trees that low).
 enum { TREE_DONE = -2147483647 - 1 };
-#ifndef WRT_WALK_NUM
-#define WRT_WALK_NUM 1
-#define WRT_WALK_DEN 2
-#endif
-#ifndef WRT_WALK_BOTH
-#define WRT_WALK_BOTH 0
-#endif
-#ifndef WRT_WALK_TOGETHER
-#define WRT_WALK_TOGETHER 1
-#endif
-__device__ __forceinline__ void walk_tree(const f32x4* __restrict__ tree, int g, int first, const TreeRay& k,
-                                          const Ray& r, bool active, float t_min, float t_max, LaneQueue& q,
-                                          Closest& best, unsigned long long& evaluated) {
-    int node = active ? 0 : TREE_DONE;
-    int sp = 0;
-    unsigned looked_at = 0u;
-    for (;;) {
-        const unsigned long long inner = __ballot(node >= 0);
-        const unsigned long long leaf = __ballot(node < 0 && node != TREE_DONE);
-        if ((inner | leaf) == 0ull) break;
-        // lanes at a leaf wait while most of the others still go down
-        const bool go_down = inner != 0ull && WRT_WALK_DEN * __popcll(leaf) < WRT_WALK_NUM * __popcll(inner | leaf);
-        if (WRT_WALK_BOTH || go_down) {
-            if (node >= 0) {
-                const f32x4* n = tree + node;
-                const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                const float upper = fminf(best.t, t_max);
-                float near0, near1;
-                const bool in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
-                const bool in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
-                int c0 = (int)__float_as_uint(q3.z), c1 = (int)__float_as_uint(q3.w);
-                if (in0 && in1) {
-                    if (near1 < near0) { const int c = c0; c0 = c1; c1 = c; }
-                    q.slot[sp * 64] = (unsigned)c1;
-                    ++sp;
-                    node = c0;
-                } else if (in0) {
-                    node = c0;
-                } else if (in1) {
-                    node = c1;
-                } else if (sp > 0) {
-                    --sp;
-                    node = (int)q.slot[sp * 64];
-                } else {
-                    node = TREE_DONE;
-                }
-            }
-        }
-        if (WRT_WALK_BOTH || !go_down) {
-            if (node < 0 && node != TREE_DONE) {
-                const int code = -1 - node;
-                const int n = (code & 7) + 1;
-                const f32x4* rec = tree + (code >> 3);
-                looked_at += (unsigned)n;
-                for (int j = 0; j < n; ++j, rec += 3) {
-                    const f32x4 a = rec[0], b = rec[1], c = rec[2];
-                    const TriTerms terms = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x);
-                    float t;
-                    if (triangle_exact(terms, t_min, t_max, t)) {
-                        const int prim = first + (int)__float_as_uint(c.y);
-                        if (t < best.t || (t == best.t && (g < best.group || (g == best.group && prim < best.prim)))) {
-                            best.t = t; best.group = g; best.prim = prim;
-                        }
-                    }
-                }
-                if (sp > 0) {
-                    --sp;
-                    node = (int)q.slot[sp * 64];
-                } else {
-                    node = TREE_DONE;
-                }
-            }
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) looked_at += (unsigned)__shfl_xor((int)looked_at, off);
-    evaluated += looked_at;
-}
 
 // ---- the same kind of hierarchy over a sphere group ---------------------------------------------
 // A leaf holds up to 8 spheres as 2 x f32x4 each: (centre, float32(r * r)) as in S.sph, (index inside
@@ -1341,7 +1264,7 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
         if (type == GROUP_SPHERES) {
             pc.sphere += (unsigned long long)n_live * (unsigned)count;
             pc.sphere_slots += 64ull * (unsigned)count;
-            if (!(WRT_WALK_TOGETHER && S.hierarchy != 0 && groups[g].tree_base >= 0 && count >= S.hierarchy &&
+            if (!(S.hierarchy != 0 && groups[g].tree_base >= 0 && count >= S.hierarchy &&
                   walk_spheres(S, groups[g], g, live, r, t_min, t_max, q, best, pc.sphere_exact)))
                 loop_spheres(S, as_uniform(S.pairs) + groups[g].pair_base, g, first, count, live, r, groups[g].c[0],
                              groups[g].c[1], groups[g].c[2], t_min, sentinel, q, best);
@@ -1360,13 +1283,8 @@ __device__ __forceinline__ void closest_hit(SceneArg S, int g_begin, int g_end, 
                 const TreeRay w = tree_ray_setup(r, pass, groups[g].reach2, groups[g].c[0], groups[g].c[1],
                                                  groups[g].c[2]);
                 if (__ballot(!w.usable) == 0ull) {
-#if WRT_WALK_TOGETHER
                     walk_tree_together(S.tree + groups[g].tree_base, groups[g].tree_leaf_shift, g, first, w, r, pass,
                                        t_min, t_max, q, best, pc.triangle_exact);
-#else
-                    walk_tree(S.tree + groups[g].tree_base, g, first, w, r, pass, t_min, t_max, q, best,
-                              pc.triangle_exact);
-#endif
                     walked = true;
                 }
             }
