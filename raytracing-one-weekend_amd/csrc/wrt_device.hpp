@@ -1029,6 +1029,7 @@ template <int KIND>
 __device__ __forceinline__ void pooled_leaf_round(const f32x4* __restrict__ tree, const unsigned* pool, int base,
                                                   int count, int leaf_shift, int first, const Ray& r, float t_min,
                                                   float t_max, LaneQueue& q) {
+    WRT_DRAIN_BEGIN(q);
     const unsigned lane = threadIdx.x & 63u;
     const int which = (int)(lane >> leaf_shift), j = (int)lane & ((1 << leaf_shift) - 1);
     const unsigned entry = which < count ? pool[base + which] : 0u;
@@ -1065,6 +1066,7 @@ __device__ __forceinline__ void pooled_leaf_round(const f32x4* __restrict__ tree
                                                     (unsigned long long)(unsigned)(first + (int)__float_as_uint(w.y)));
         }
     }
+    WRT_DRAIN_END(q);
 }
 
 template <int KIND = GROUP_TRIANGLES>
