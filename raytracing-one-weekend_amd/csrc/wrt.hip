@@ -597,7 +597,10 @@ static __device__ __align__(256) unsigned char scratch[STATIC_COUNTER_BYTES + ST
 // The bounce kernel's instances: 0 everything but the hierarchy walk, 1 everything, 2 scenes without
 // triangle groups (no spill scratch at all: measured 6.6 % faster on a 484-sphere scene than instance
 // 0).  An instance without the sphere loops for scenes whose sphere groups are all small measured
-// 3 % slower than instance 0 on a mesh scene (more spills, not fewer) and is not kept.
+// 3 % slower than instance 0 on a mesh scene (more spills, not fewer), one with the walk and without
+// the triangle code 1 % slower than instance 1 on the 484-sphere scene walked (the walk's own registers
+// bring the spill scratch back): not kept.  Instance 1 runs only when a group of the scene is walked
+// at the current setting of wrt_set_hierarchy.
 static constexpr int RENDER_INSTANCES = 3;
 typedef void (*RenderKernel)(const RenderLaunch);
 static RenderKernel render_instance(int k) {
@@ -633,6 +636,7 @@ struct wrt_ctx {
     SceneRec scene;
     bool committed = false;
     int render_instance = 0;     // chosen at commit from the kinds of groups the scene has (see render_instance())
+    int largest_tree_group = 0;  // primitives of the largest group that has a hierarchy (0: none has)
     // device copies
     void* d_blob = nullptr;
     size_t blob_bytes = 0;
@@ -1454,6 +1458,9 @@ int wrt_scene_commit(wrt_ctx* ctx) {
         bool triangles = false;
         for (const GroupRec& g : ctx->h_groups) triangles = triangles || g.type == GROUP_TRIANGLES;
         ctx->render_instance = triangles ? 0 : 2;
+        ctx->largest_tree_group = 0;
+        for (const GroupRec& g : ctx->h_groups)
+            if (g.tree_base >= 0 && g.count > ctx->largest_tree_group) ctx->largest_tree_group = g.count;
     }
     ctx->committed = true;
     return WRT_OK;
@@ -1483,7 +1490,8 @@ static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int
         HIP_TRY(ctx, hipMemsetAsync(next_batch, 0, sizeof(unsigned long long), st));
         A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
         A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
-        const int instance = ctx->hierarchy != 0 ? 1 : ctx->render_instance;
+        const bool walks = ctx->hierarchy != 0 && ctx->largest_tree_group >= ctx->hierarchy;
+        const int instance = walks ? 1 : ctx->render_instance;
         void (*const kernel)(const RenderLaunch) = render_instance(instance);
         int blocks = ctx->cus * ctx->render_blocks_per_cu[instance];
         const long long blocks_wanted = (A.n_batches + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
