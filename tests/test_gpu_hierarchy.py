@@ -214,6 +214,35 @@ def test_groups_with_leaves_of_eight(kind):
         assert 0 < st_on["sphere_evaluations"] < 0.5 * st_on["sphere_pairs"]
 
 
+@pytest.mark.parametrize("n_copies,n_per_group", [(6, 40), (40, 24)])
+def test_ties_between_walked_groups(n_copies, n_per_group):
+    """The same spheres and triangles in many groups, every one of them walked: each hit is a tie between
+    groups, which the earliest group wins whatever order the walks run in; with more than 32 large groups
+    the further ones are walked in scene order, out of the per-lane pass over the groups."""
+    from tests.test_gpu_random_scenes import layered_scene
+    from weekend_raytracer import main
+    scene = layered_scene(n_copies, n_per_group, seed=n_copies)
+    w, h, s, b = 48, 30, 2, 6
+    want = numpy_path.render(scene, w, h, s, b, seed=78)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    frame = main.Frame(objs, hierarchy=16)
+    frame.ctx.stats_reset()
+    import torch
+    paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
+    frame.accumulate(w, h, 0, s, b, 78, paths=paths)
+    stats = frame.ctx.stats()
+    frame.ctx.close()
+    got = paths.cpu().numpy()
+    assert np.array_equal(got[:, :3], want["path_colours"])
+    from weekend_raytracer import _native
+    assert np.array_equal(got[:, 3].astype(np.int32) % _native.SURVIVOR_MARK, want["segments"])
+    # walked, not looped: fewer primitives evaluated than pairs examined (two dozen large triangles in a
+    # group leave little to skip)
+    assert 0 < stats["triangle_evaluations"] < 0.8 * stats["triangle_pairs"]
+    assert 0 < stats["sphere_evaluations"] < 0.8 * stats["sphere_pairs"]
+
+
 # ---- sphere groups ---------------------------------------------------------------------------
 @pytest.mark.parametrize("field,size", [
     (None, (320, 180, 6, 10)),                # the shipped 187-sphere field (+ ground and three unit spheres)
