@@ -1028,7 +1028,7 @@ static_assert(POOL_ROOM >= 16 + 128, "a step adds at most 128 leaves to fewer th
 template <int KIND>
 __device__ __forceinline__ void pooled_leaf_round(const f32x4* __restrict__ tree, const unsigned* pool, int base,
                                                   int count, int leaf_shift, int first, const Ray& r, float t_min,
-                                                  float t_max, LaneQueue& q) {
+                                                  float t_max, LaneQueue& q, unsigned long long& evaluated) {
     WRT_DRAIN_BEGIN(q);
     const unsigned lane = threadIdx.x & 63u;
     const int which = (int)(lane >> leaf_shift), j = (int)lane & ((1 << leaf_shift) - 1);
@@ -1036,6 +1036,7 @@ __device__ __forceinline__ void pooled_leaf_round(const f32x4* __restrict__ tree
     const unsigned owner = entry >> 26;
     const int code = (int)(entry & 0x3ffffffu);
     const bool have = which < count && j <= (code & 7);
+    evaluated += (unsigned)__popcll(__ballot(have));
     const int owner4 = (int)owner * 4;
     Ray b;
     b.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
@@ -1091,7 +1092,6 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
     int node = active ? 0 : TREE_DONE;
     int top = 0, held = 0;
     int pooled = 0;                      // leaves in the pool
-    unsigned looked_at = 0u;
     for (;;) {
         const unsigned long long busy = __ballot(node != TREE_DONE);
         if (busy == 0ull) break;                               // an idle lane holds no entries
@@ -1138,10 +1138,13 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
         float near0 = 0.0f, near1 = 0.0f;
         int c0 = 0, c1 = 0;
         if (node >= 0) {
-            const f32x4* n = tree + node;
+            // (an unsigned 32-bit byte offset from the uniform base: one shift, no 64-bit address arithmetic)
+            const f32x4* n = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tree) + (unsigned)node * 16u);
             const f32x4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            const float upper = fminf(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)),
-                                      KIND == GROUP_SPHERES ? t_max + 1.0f : t_max);
+            // the nearer of the ray's best hit so far and the end of its range (v_med3_f32 with -inf: a
+            // minimum that takes the two numbers as they are)
+            const float upper = __builtin_amdgcn_fmed3f(from_ordered_bits((unsigned)(q.share_best[owner] >> 32)),
+                                                        KIND == GROUP_SPHERES ? t_max + 1.0f : t_max, -__builtin_inff());
             in0 = tree_box(k, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.x, t_min, upper, near0);
             in1 = tree_box(k, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.y, t_min, upper, near1);
             c0 = (int)__float_as_uint(q3.z); c1 = (int)__float_as_uint(q3.w);
@@ -1153,14 +1156,12 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(leaves0 >> 32),
                                       __builtin_amdgcn_mbcnt_lo((unsigned)leaves0, 0u));
                 pool[pooled + rank] = (owner << 26) | (unsigned)(-1 - c0);
-                looked_at += (unsigned)((-1 - c0) & 7) + 1u;
             }
             pooled += (int)__popcll(leaves0);
             if (leaf1) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(leaves1 >> 32),
                                       __builtin_amdgcn_mbcnt_lo((unsigned)leaves1, 0u));
                 pool[pooled + rank] = (owner << 26) | (unsigned)(-1 - c1);
-                looked_at += (unsigned)((-1 - c1) & 7) + 1u;
             }
             pooled += (int)__popcll(leaves1);
         }
@@ -1187,17 +1188,15 @@ __device__ __forceinline__ void walk_tree_together(const f32x4* __restrict__ tre
         while (pooled >= drain_at) {
             const int count = pooled < round_leaves ? pooled : round_leaves;
             pooled -= count;
-            pooled_leaf_round<KIND>(tree, pool, pooled, count, leaf_shift, first, r, t_min, t_max, q);
+            pooled_leaf_round<KIND>(tree, pool, pooled, count, leaf_shift, first, r, t_min, t_max, q, evaluated);
         }
     }
     // what is left in the pool
-    if (pooled > 0) pooled_leaf_round<KIND>(tree, pool, 0, pooled, leaf_shift, first, r, t_min, t_max, q);
+    if (pooled > 0) pooled_leaf_round<KIND>(tree, pool, 0, pooled, leaf_shift, first, r, t_min, t_max, q, evaluated);
     const unsigned long long won = q.share_best[lane];
     if (active && won != start) {
         best.t = from_ordered_bits((unsigned)(won >> 32)); best.group = g; best.prim = (int)(unsigned)won;
     }
-    for (int off = 32; off > 0; off >>= 1) looked_at += (unsigned)__shfl_xor((int)looked_at, off);
-    evaluated += looked_at;
 }
 
 // A sphere group through its hierarchy: the few spheres kept out of the tree first, each lane on its
