@@ -397,7 +397,7 @@ def main():
                 "pairs_per_launch": {"triangle": stats["triangle_pairs"] // max(1, launches),
                                      "sphere": stats["sphere_pairs"] // max(1, launches),
                                      "cull": stats["cull_tests"] // max(1, launches)},
-                # the same launch against the HBM roofline: SURVEY-style algorithmic bytes (48 B of ray state per
+                # the same launch against the HBM roofline: algorithmic bytes (48 B of ray state per
                 # segment as the reference moves it, 12 B accumulated per primary ray); the kernel itself keeps
                 # ray state in registers and writes 16 B per path
                 "hbm_view": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s",
