@@ -100,6 +100,18 @@ def test_bunny_scene_full_size():
     assert stats["triangle_pairs"] % 644 == 0 and 0 < stats["triangle_pairs"] <= segments * 644
 
 
+@pytest.mark.parametrize("hierarchy", [False, 64])
+def test_cloth_bunny_scene_full_size(hierarchy):
+    """The textured configuration: textured bunny + UV-mapped picnic cloth, 1920x1080, 64 spp, 10 bounces (the
+    reference has no strength maps, so none are applied); every pair examined and, apart, both meshes walked
+    through their hierarchies."""
+    from weekend_raytracer import scenes
+    w, h, s, b, seed = 1920, 1080, 64, 10, 1234
+    flat, p, a, stats = full_frame(scenes.cloth_bunny_scene, w, h, s, b, seed, hierarchy=hierarchy)
+    check_full_frame(flat, p, a, stats, w, h, s, b, seed, None, sampled=3000)
+    assert 0 < stats["triangle_evaluations"] < stats["triangle_pairs"]
+
+
 @pytest.mark.parametrize("hierarchy", [False, True])
 def test_cow_teapot_field_full_size(hierarchy):
     """The multi-GPU benchmark configuration's per-GPU workload: cow.obj + teapot.obj (12 124 triangles) + the
