@@ -206,3 +206,21 @@ def test_edge_cases(ctx):
     ctx.render(8, 8, 0, 1, 4, 1, accum)
     st = ctx.stats()
     assert list(st["rays_per_bounce"][:5]) == [64] * 5 and not accum.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("w,h,s", [(1, 1, 1), (1, 1, 7), (13, 7, 3), (8, 8, 1), (9, 17, 2), (65, 3, 1)])
+def test_ragged_frames_and_an_empty_scene(w, h, s):
+    """Frames that are not whole 8 x 8 tiles (down to one pixel, one sample), on the demo scene and on a
+    scene without any group (every ray ends in the sky: reference main.py:203-209): every path equals the oracle's."""
+    from tests.test_gpu_reject import Flat
+    from weekend_raytracer import main
+    base = helpers.golden_scene(helpers.golden("frame_demo"))
+    for scene in (base, dict(base, groups=[])):
+        want = numpy_path.render(scene, w, h, s, 6, seed=31)
+        objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+                {i: Flat(m) for i, m in scene["materials"].items()})
+        got = main.render_frame(objs, w, h, s, 6, seed=31, want_paths=True)
+        assert np.array_equal(got["path_colours"], want["path_colours"])
+        assert np.array_equal(got["segments"], want["segments"])
+        assert np.array_equal(got["counts"], want["counts"])
+        assert np.array_equal(got["image"], want["image"])
