@@ -215,7 +215,7 @@ int wrt_set_triangle_reject(wrt_ctx* ctx, int on);
    by a bound on that evaluation's float32 error, so the closest hit (t, primitive, tie order) is
    the same bit for bit; the work done is not the reference's, and throughput in this mode is to
    be reported apart from the brute-force figure.  On one MI355X the walk overtakes the
-   brute-force loops at about 1000 triangles or 500 spheres per group.  Takes effect with the
+   brute-force loops at about 600 triangles or 400 spheres per group.  Takes effect with the
    next render or intersect. */
 int wrt_set_hierarchy(wrt_ctx* ctx, int min_primitives);
 
