@@ -461,12 +461,15 @@ __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, i
 
 // one vote for two spheres; the lanes that have to look at one note it down
 // (index + 1 == count: the second half repeats the group's last sphere and is left out)
-__device__ __forceinline__ void sphere_step(const SpherePair& s, int index, int count, float thr,
-                                            const SphereBoundRay& r2, LaneQueue& q) {
+// (the queues are looked at for room only after a step that added to them)
+__device__ __forceinline__ void sphere_step(SceneArg S, const SpherePair& s, int index, int count, float thr,
+                                            const SphereBoundRay& r2, LaneQueue& q, int g, int first, const Ray& r,
+                                            float t_min, float sentinel, Closest& best) {
     const f32x2 d = sphere_discriminant_bound2(r2, s);
     if (__ballot(fmaxf(d.x, d.y) > thr) != 0ull) {
         push(q, d.x > thr, index);
         push(q, d.y > thr && index + 1 < count, index + 1);
+        if (short_of_room(q, 2)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
     }
 }
 
@@ -488,29 +491,28 @@ __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* 
     const int pairs = (count + 1) >> 1;
     SphereQuad A = fetch_sphere_quad(records), B;
     int j = 0;
+#define WRT_STEP(rec, at) sphere_step(S, rec, at, count, thr, r2, q, g, first, r, t_min, sentinel, best)
     for (; j + 3 < pairs; j += 4) {
         WRT_SCALAR_LOADS_ARRIVED();
-        if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
         WRT_PIN();
-        sphere_step(A.a, 2 * j, count, thr, r2, q);
-        sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
+        WRT_STEP(A.a, 2 * j);
+        WRT_STEP(A.b, 2 * j + 2);
         WRT_SCALAR_LOADS_ARRIVED();
-        if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         A = fetch_sphere_quad(records + 8);
         WRT_PIN();
-        sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
-        sphere_step(B.b, 2 * j + 6, count, thr, r2, q);
+        WRT_STEP(B.a, 2 * j + 4);
+        WRT_STEP(B.b, 2 * j + 6);
         records += 8;
     }
     WRT_SCALAR_LOADS_ARRIVED();
     if (j < pairs) {                       // up to three pairs left: A holds two of them
-        if (short_of_room(q, 6)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
         B = fetch_sphere_quad(records + 4);
-        sphere_step(A.a, 2 * j, count, thr, r2, q);
-        if (j + 1 < pairs) sphere_step(A.b, 2 * j + 2, count, thr, r2, q);
-        if (j + 2 < pairs) sphere_step(B.a, 2 * j + 4, count, thr, r2, q);
+        WRT_STEP(A.a, 2 * j);
+        if (j + 1 < pairs) WRT_STEP(A.b, 2 * j + 2);
+        if (j + 2 < pairs) WRT_STEP(B.a, 2 * j + 4);
     }
+#undef WRT_STEP
     drain_spheres(S, q, g, first, r, t_min, sentinel, best);
 }
 
@@ -539,10 +541,9 @@ __device__ __forceinline__ void loop_spheres_staged(SceneArg S, const f32x4* rec
         if (2 * base + (int)lane < 2 * pairs) tile[lane] = records[2 * base + (int)lane];
         const int n = pairs - base < 32 ? pairs - base : 32;
         for (int j = 0; j < n; ++j) {
-            if (short_of_room(q, 2)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
             const f32x4 a = tile[2 * j], b = tile[2 * j + 1];
             const SpherePair s = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
-            sphere_step(s, 2 * (base + j), count, thr, r2, q);
+            sphere_step(S, s, 2 * (base + j), count, thr, r2, q, g, first, r, t_min, sentinel, best);
         }
     }
     drain_spheres(S, q, g, first, r, t_min, sentinel, best);
