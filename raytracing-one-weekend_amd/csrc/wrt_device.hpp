@@ -62,7 +62,7 @@ struct MaterialRec {         // per material index, gathered per lane
     float fuzz;              // float32(fuzziness): multiplies a float32 vector (materials.py:274)
     int fuzzy;               // fuzziness > 0.0001 evaluated on the Python float
     float ior;               // numpy.full(n, ior, dtype=single) (materials.py:319)
-    int tree_leaf_shift;     // groups with a hierarchy: a leaf holds up to 1 << this many primitives (2 or 3)
+    int pad;
 };
 
 struct TextureRec {
