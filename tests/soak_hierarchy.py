@@ -1,0 +1,155 @@
+"""Randomised soak of the optional hierarchy on the GPU box: the shipped meshes (bunny, cow, teapot) and
+sphere fields under random similarity transforms (scale 0.01 .. 100, any rotation, offsets up to 2000
+units), seen by random cameras (some far away, some inside the meshes' bounds, some looking along
+the meshes' flanks), rendered with every group walked and with the uniform loops; every path record
+must be equal bit for bit.
+
+    python tests/soak_hierarchy.py [first_seed] [n_scenes] [seconds]
+
+Not collected by pytest (a soak, not a test of fixed length).  Exit status 1 if any path differed.
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "raytracing-one-weekend_amd"))
+import numpy as np  # noqa: E402
+
+from oracle import numpy_path  # noqa: E402  (camera basis only)
+from tests.test_gpu_reject import Flat  # noqa: E402
+from weekend_raytracer import _flatten, main, scenes  # noqa: E402
+
+
+def base_scenes():
+    out = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for fn in (scenes.ray_group_triangle_group_bunny_scene, scenes.cow_teapot_field_scene, scenes.cloth_bunny_scene):
+            out.append(_flatten.flatten(*fn(16 / 9), main.HORIZON_COLOUR, main.SKY_COLOUR))
+        out.append(_flatten.flatten(*scenes.cover_scene(16 / 9, scenes.sphere_field_records(480)),
+                                    main.HORIZON_COLOUR, main.SKY_COLOUR))
+    return out
+
+
+def rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    a, b, c, d = q
+    return np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                     [2 * (b * c + a * d), a * a - b * b + c * c - d * d, 2 * (c * d - a * b)],
+                     [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
+
+
+def transformed(flat, rng):
+    scale = float(10.0 ** rng.uniform(-2, 2))
+    R = rotation(rng) if rng.random() < 0.8 else np.eye(3)
+    offset = rng.uniform(-1, 1, 3) * float(10.0 ** rng.uniform(-1, 3.3))
+
+    def move(p):
+        return (np.asarray(p, np.float64) @ R.T) * scale + offset
+
+    groups, centres = [], []
+    for g in flat["groups"]:
+        g = dict(g)
+        if g["type"] == "spheres":
+            g["centres"] = move(g["centres"]).astype(np.single)
+            g["radii"] = (np.asarray(g["radii"], np.float64) * scale).astype(np.single)
+            small = g["radii"] < 50 * scale
+            if small.any():
+                centres.append(g["centres"][small].astype(np.float64))
+        elif g["type"] == "triangles":
+            p0 = move(g["pt0"])
+            p1 = move(np.asarray(g["pt0"], np.float64) + g["A"])
+            p2 = move(np.asarray(g["pt0"], np.float64) + g["B"])
+            g["pt0"] = p0.astype(np.single)
+            g["A"] = (p1 - p0).astype(np.single)
+            g["B"] = (p2 - p0).astype(np.single)
+            for k in ("n0", "n1", "n2"):
+                g[k] = (np.asarray(g[k], np.float64) @ R.T).astype(np.single)
+            pts = np.concatenate([p0, p1, p2])
+            bc = pts.mean(axis=0).astype(np.single)
+            g["bounds_centre"] = bc
+            g["bounds_radius"] = np.single(np.max(np.linalg.norm(pts - bc, axis=1)) * 1.01)
+            centres.append(pts)
+        else:
+            continue                                   # (no disks in these scenes)
+        groups.append(g)
+    pts = np.concatenate(centres)
+    middle, extent = pts.mean(axis=0), float(np.max(np.linalg.norm(pts - pts.mean(axis=0), axis=1)))
+    kind = rng.integers(0, 4)
+    direction = rng.normal(size=3)
+    direction /= np.linalg.norm(direction)
+    if kind == 0:        # from outside
+        pos = middle + direction * extent * float(rng.uniform(1.2, 4.0))
+        target = middle + rng.normal(size=3) * 0.2 * extent
+    elif kind == 1:      # from far away, narrow view
+        pos = middle + direction * extent * float(rng.uniform(8.0, 40.0))
+        target = middle
+    elif kind == 2:      # from inside the bounds
+        pos = middle + rng.normal(size=3) * 0.3 * extent
+        target = middle + direction * extent
+    else:                # skimming past a point of the scene
+        at = pts[rng.integers(0, len(pts))]
+        pos = at + direction * extent * float(rng.uniform(0.5, 2.0))
+        side = np.cross(direction, rng.normal(size=3))
+        target = at + side / np.linalg.norm(side) * extent * float(rng.uniform(0.0, 0.02))
+    fov = float(rng.uniform(3.0, 12.0)) if kind == 1 else float(rng.uniform(20.0, 90.0))
+    focus = float(np.linalg.norm(target - pos))
+    cam = numpy_path.camera_basis(pos, target, focus, float(rng.choice([0.0, 0.02 * extent])), 16 / 9, fov)
+    return dict(flat, camera=cam, groups=groups), scale
+
+
+def one_scene(bases, seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    scene, scale = transformed(bases[int(rng.integers(0, len(bases)))], rng)
+    w, h, s, b = 192, 108, 2, int(rng.integers(2, 9))
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    out, evaluated = [], []
+    for hierarchy in (16, 0):
+        frame = main.Frame(objs, hierarchy=hierarchy)
+        frame.ctx.stats_reset()
+        paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
+        frame.accumulate(w, h, 0, s, b, seed, paths=paths)
+        st = frame.ctx.stats()
+        evaluated.append((int(st["triangle_evaluations"]), int(st["sphere_evaluations"])))
+        out.append(paths.cpu().numpy().view(np.uint32))
+        frame.ctx.close()
+    same = np.all(out[0] == out[1], axis=1)
+    hits = float(np.mean(out[1][:, 3].view(np.float32) % 100 > 1))
+    if not same.all():
+        print(f"MISMATCH seed {seed}: scale {scale:.3g}, {100 * same.mean():.4f} % of paths equal", flush=True)
+    # walked: sphere groups evaluate through the walk only; triangle walks look at fewer triangles than the loops' reject
+    did_walk = evaluated[0][1] > 0 or evaluated[0][0] < 0.7 * evaluated[1][0]
+    return (0 if same.all() else 1), w * h * s, hits, did_walk
+
+
+def run(first_seed, n_scenes, seconds):
+    bases = base_scenes()
+    began = time.time()
+    bad = paths = done = walked = 0
+    bounced = 0.0
+    for seed in range(first_seed, first_seed + n_scenes):
+        if time.time() - began > seconds:
+            break
+        b, p, hits, did_walk = one_scene(bases, seed)
+        bad += b
+        paths += p
+        bounced += hits
+        walked += int(did_walk)
+        done += 1
+        if done % 20 == 0:
+            print(f"{done} scenes, {paths} paths, {bad} mismatches, {walked} with walks, "
+                  f"{100 * bounced / done:.0f} % of paths hit something, {time.time() - began:.0f} s", flush=True)
+    print(f"soak: {done} scenes (seeds {first_seed}..{first_seed + done - 1}), {paths} paths each way, {walked} scenes "
+          f"with walks, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    args = [int(v) for v in sys.argv[1:]]
+    sys.exit(run(args[0] if args else 50000, args[1] if len(args) > 1 else 100, args[2] if len(args) > 2 else 240))
