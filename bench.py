@@ -405,10 +405,11 @@ def main():
                                                (kernel_ms * 1e-3) / 1e9, 2)
                              if kernel_ms > 0 else 0.0},
                 "lane_efficiency": {
+                    # (with the hierarchy, walked groups spend no lane slots in loops: no figure then)
                     "triangle_loops": round(stats["triangle_pairs"] / stats["triangle_lane_slots"], 4)
-                    if stats["triangle_lane_slots"] else None,
+                    if stats["triangle_lane_slots"] and not args.hierarchy else None,
                     "sphere_loops": round(stats["sphere_pairs"] / stats["sphere_lane_slots"], 4)
-                    if stats["sphere_lane_slots"] else None},
+                    if stats["sphere_lane_slots"] and not args.hierarchy else None},
                 "note": "FP32 vector (VALU) roofline: this path is not a dense contraction, MFMA is not used; "
                         "achieved = 45/ray-triangle pair + 19/ray-sphere pair + 14/cull test as the reference "
                         "evaluates them, over the kernel time; executed = the cheaper conservative tests the "

@@ -89,8 +89,9 @@ typedef struct wrt_stats {
     uint64_t triangle_pairs;   /* (ray, triangle) pairs after the bounding-sphere cull */
     uint64_t cull_tests;       /* (ray, triangle group) bounding-sphere tests */
     uint64_t disk_pairs;
-    /* lane slots spent in the wave-uniform group loops (64 x primitives per run);
-       pairs evaluated there / slots = lane efficiency of the dominant loops */
+    /* lane slots spent in the wave-uniform group loops (64 x primitives per run; none for a
+       group walked through its hierarchy); pairs evaluated there / slots = lane efficiency of
+       the dominant loops */
     uint64_t sphere_lane_slots;
     uint64_t triangle_lane_slots;
     /* clock tallies of the bounce kernel, zero unless the library was built with

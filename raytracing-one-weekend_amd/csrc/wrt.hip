@@ -369,7 +369,6 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
             since = WRT_CLOCK();
             if (TRIANGLES && (!LARGE_SPHERES || type == GROUP_TRIANGLES)) {
                 pc.triangle += (unsigned long long)run_n * (unsigned)count;
-                pc.triangle_slots += 64ull * (unsigned)count;
                 const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach,
                                                            ugroups[run_g].reject_eps, ugroups[run_g].c[0],
                                                            ugroups[run_g].c[1], ugroups[run_g].c[2]);
@@ -383,6 +382,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                         walked = true;
                     }
                 }
+                if (!walked) pc.triangle_slots += 64ull * (unsigned)count;     // lane slots of the uniform loops
                 if (walked) {
                 } else if (S.prefilter && __ballot(!k.usable) == 0ull)
                     loop_triangles_rejecting(S, as_uniform(S.bounds) + ugroups[run_g].bound_base, run_g, first, count,
@@ -392,11 +392,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                 WRT_TALLY(2, since);
             } else if (LARGE_SPHERES) {
                 pc.sphere += (unsigned long long)run_n * (unsigned)count;
-                pc.sphere_slots += 64ull * (unsigned)count;
                 const bool walked = WALK && S.hierarchy != 0 && ugroups[run_g].tree_base >= 0 &&
                                     count >= S.hierarchy &&
                                     walk_spheres(S, ugroups[run_g], run_g, mine, ray, t_min, t_max, queue, best, pc.sphere_exact);
                 if (!walked) {
+                    pc.sphere_slots += 64ull * (unsigned)count;
 #if WRT_STAGE_SPHERES_IN_LDS
                     __shared__ f32x4 staged[RENDER_BLOCK / 64][64];
                     loop_spheres_staged(S, S.pairs + ugroups[run_g].pair_base, staged[threadIdx.x >> 6], run_g, first,
