@@ -56,8 +56,10 @@ def run(name):
     if st["triangle_pairs"]:
         print(f"  triangle pairs fully evaluated: {st['triangle_evaluations'] / st['triangle_pairs']:.4f} of all, "
               f"{st['triangle_evaluations'] / max(1, st['cull_tests']):.2f} per (ray, group)")
-    print(f"  lane efficiency tri {st['triangle_pairs'] / max(1, st['triangle_lane_slots']):.3f} "
-          f"sph {st['sphere_pairs'] / max(1, st['sphere_lane_slots']):.3f}")
+    # (walked groups spend no lane slots in loops: with WRT_HIERARCHY set the figures cover the remaining loops' slots only)
+    if not int(os.environ.get("WRT_HIERARCHY", "0")):
+        print(f"  lane efficiency tri {st['triangle_pairs'] / max(1, st['triangle_lane_slots']):.3f} "
+              f"sph {st['sphere_pairs'] / max(1, st['sphere_lane_slots']):.3f}")
     ctx.close()
 
 
