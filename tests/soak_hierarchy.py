@@ -1,7 +1,7 @@
 """Randomised soak of the optional hierarchy on the GPU box: the shipped meshes (bunny, cow, teapot) and
 sphere fields under random similarity transforms (scale 0.01 .. 100, any rotation, offsets up to 2000
-units), seen by random cameras (some far away, some inside the meshes' bounds, some looking along
-the meshes' flanks), rendered with every group walked and with the uniform loops; every path record
+units), seen by random cameras (some far away, some inside the meshes' bounds, some skimming past a
+vertex, some lying in the plane of a triangle and looking along it), rendered with every group walked and with the uniform loops; every path record
 must be equal bit for bit.
 
     python tests/soak_hierarchy.py [first_seed] [n_scenes] [seconds]
@@ -79,7 +79,10 @@ def transformed(flat, rng):
         groups.append(g)
     pts = np.concatenate(centres)
     middle, extent = pts.mean(axis=0), float(np.max(np.linalg.norm(pts - pts.mean(axis=0), axis=1)))
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
+    tri_groups = [g for g in groups if g["type"] == "triangles"]
+    if kind == 4 and not tri_groups:
+        kind = 3
     direction = rng.normal(size=3)
     direction /= np.linalg.norm(direction)
     if kind == 0:        # from outside
@@ -91,6 +94,18 @@ def transformed(flat, rng):
     elif kind == 2:      # from inside the bounds
         pos = middle + rng.normal(size=3) * 0.3 * extent
         target = middle + direction * extent
+    elif kind == 4:      # in the plane of one of the triangles (or a hair off it), looking along the plane
+        g = tri_groups[int(rng.integers(0, len(tri_groups)))]
+        j = int(rng.integers(0, g["pt0"].shape[0]))
+        P0, A, B = (np.asarray(g[k][j], np.float64) for k in ("pt0", "A", "B"))
+        n = np.cross(A, B)
+        n /= max(np.linalg.norm(n), 1e-300)
+        a, b2 = rng.uniform(-3, 3, 2)
+        lift = float(rng.choice([0.0, 1e-7, 1e-5, 1e-3])) * extent * float(rng.choice([-1.0, 1.0]))
+        pos = P0 + a * A + b2 * B + lift * n + (A + B) / max(np.linalg.norm(A + B), 1e-300) * extent * float(rng.uniform(0.0, 1.5))
+        target = P0 + float(rng.uniform(0, 1)) * A + float(rng.uniform(0, 1)) * B
+        if np.linalg.norm(target - pos) < 1e-6 * extent:
+            pos = pos + A * 5.0
     else:                # skimming past a point of the scene
         at = pts[rng.integers(0, len(pts))]
         pos = at + direction * extent * float(rng.uniform(0.5, 2.0))
