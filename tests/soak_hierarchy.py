@@ -4,7 +4,10 @@ units), seen by random cameras (some far away, some inside the meshes' bounds, s
 vertex, some lying in the plane of a triangle and looking along it), rendered with every group walked and with the uniform loops; every path record
 must be equal bit for bit.
 
-    python tests/soak_hierarchy.py [first_seed] [n_scenes] [seconds]
+    python tests/soak_hierarchy.py [first_seed] [n_scenes] [seconds] [--reject]
+
+--reject: the same configurations through the uniform loops with the conservative per-triangle test
+(wrt_set_triangle_reject) switched on and off instead.
 
 Not collected by pytest (a soak, not a test of fixed length).  Exit status 1 if any path differed.
 """
@@ -117,7 +120,7 @@ def transformed(flat, rng):
     return dict(flat, camera=cam, groups=groups), scale
 
 
-def one_scene(bases, seed):
+def one_scene(bases, seed, what="hierarchy"):
     import torch
     rng = np.random.default_rng(seed)
     scene, scale = transformed(bases[int(rng.integers(0, len(bases)))], rng)
@@ -125,25 +128,33 @@ def one_scene(bases, seed):
     objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
             {i: Flat(m) for i, m in scene["materials"].items()})
     out, evaluated = [], []          # (evaluated: lane slots of the uniform loops)
-    for hierarchy in (16, 0):
-        frame = main.Frame(objs, hierarchy=hierarchy)
+    for variant in (True, False):
+        # "hierarchy": every group walked against the loops; "reject": the loops with and without the
+        # conservative per-triangle test in front of the full evaluation
+        frame = main.Frame(objs, hierarchy=16 if (what == "hierarchy" and variant) else 0)
+        if what == "reject":
+            frame.ctx.set_triangle_reject(variant)
         frame.ctx.stats_reset()
         paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
         frame.accumulate(w, h, 0, s, b, seed, paths=paths)
         st = frame.ctx.stats()
         evaluated.append(int(st["triangle_lane_slots"]) + int(st["sphere_lane_slots"]))
         out.append(paths.cpu().numpy().view(np.uint32))
+        if what == "reject":
+            evaluated[-1] = -int(st["triangle_evaluations"])      # (rejecting: some pairs reach the full evaluation; off: none is counted)
+            frame.ctx.set_triangle_reject(True)
         frame.ctx.close()
     same = np.all(out[0] == out[1], axis=1)
     hits = float(np.mean(out[1][:, 3].view(np.float32) % 100 > 1))
     if not same.all():
         print(f"MISMATCH seed {seed}: scale {scale:.3g}, {100 * same.mean():.4f} % of paths equal", flush=True)
     # walked: fewer lane slots spent in the uniform loops than without the hierarchy
+    # (reject: the rejecting loop ran, which is the one that counts the pairs it lets through)
     did_walk = evaluated[0] < evaluated[1]
     return (0 if same.all() else 1), w * h * s, hits, did_walk
 
 
-def run(first_seed, n_scenes, seconds):
+def run(first_seed, n_scenes, seconds, what="hierarchy"):
     bases = base_scenes()
     began = time.time()
     bad = paths = done = walked = 0
@@ -151,20 +162,21 @@ def run(first_seed, n_scenes, seconds):
     for seed in range(first_seed, first_seed + n_scenes):
         if time.time() - began > seconds:
             break
-        b, p, hits, did_walk = one_scene(bases, seed)
+        b, p, hits, did_walk = one_scene(bases, seed, what)
         bad += b
         paths += p
         bounced += hits
         walked += int(did_walk)
         done += 1
         if done % 20 == 0:
-            print(f"{done} scenes, {paths} paths, {bad} mismatches, {walked} with walks, "
+            print(f"{what}: {done} scenes, {paths} paths, {bad} mismatches, {walked} with {'walks' if what == 'hierarchy' else 'rejecting loops'}, "
                   f"{100 * bounced / done:.0f} % of paths hit something, {time.time() - began:.0f} s", flush=True)
-    print(f"soak: {done} scenes (seeds {first_seed}..{first_seed + done - 1}), {paths} paths each way, {walked} scenes "
-          f"with walks, {bad} mismatches")
+    print(f"soak ({what}): {done} scenes (seeds {first_seed}..{first_seed + done - 1}), {paths} paths each way, {walked} scenes "
+          f"with {'walks' if what == 'hierarchy' else 'rejecting loops'}, {bad} mismatches")
     return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    args = [int(v) for v in sys.argv[1:]]
-    sys.exit(run(args[0] if args else 50000, args[1] if len(args) > 1 else 100, args[2] if len(args) > 2 else 240))
+    what = "reject" if "--reject" in sys.argv else "hierarchy"
+    args = [int(v) for v in sys.argv[1:] if not v.startswith("--")]
+    sys.exit(run(args[0] if args else 50000, args[1] if len(args) > 1 else 100, args[2] if len(args) > 2 else 240, what))
