@@ -340,6 +340,10 @@ def main():
         # for bit), so sqrt(mean) can be NaN in a handful of pixels, exactly as numpy.sqrt gives the reference.
         bad_pixels = int((~torch.isfinite(image).all(dim=2)).sum().item())
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        # mean wavefront lifetime in shader clock cycles over the average kernel duration (the wavefronts are
+        # resident for the whole launch; the chip's clock domains differ by a few per cent, this is their mean)
+        clock_mhz = round(float(stats["clock_ticks"][0]) / max(1, stats["wavefronts"]) / (kernel_ms / max(1, launches)) / 1e3, 1) \
+            if kernel_ms > 0 else None
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -384,6 +388,9 @@ def main():
                 "frac_executed": round(executed_flops / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)
                 if kernel_ms > 0 else 0.0,
                 "traffic": traffic,
+                # the shader clock the kernel ran at (the peak assumes 2400 MHz) and the fraction priced at that clock
+                "shader_clock_mhz": clock_mhz,
+                "frac_at_clock": round(achieved / FP32_VECTOR_PEAK_TFLOPS * 2400.0 / clock_mhz, 4) if clock_mhz else None,
                 "kernel": "k_render",
                 "kernel_ms_avg": round(kernel_ms / max(1, launches), 4),
                 "launches": launches,

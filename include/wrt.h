@@ -94,11 +94,11 @@ typedef struct wrt_stats {
        the dominant loops */
     uint64_t sphere_lane_slots;
     uint64_t triangle_lane_slots;
-    /* clock tallies of the bounce kernel, zero unless the library was built with
-       -DWRT_TIMING=1 (shader clock cycles): [0] sum of the wavefronts' lifetimes,
-       [1] longest lifetime, [2] in triangle loops, [3] in sphere loops, [4] shading,
-       [5] refilling lanes, [6] per-lane group walk, [7] working candidate queues off
-       (part of [2] and [3]) */
+    /* clock tallies of the bounce kernel in shader clock cycles: [0] sum of the wavefronts'
+       lifetimes, [1] longest lifetime (over the kernel's duration: the clock it ran at); and,
+       zero unless the library was built with -DWRT_TIMING=1: [2] in triangle loops, [3] in
+       sphere loops, [4] shading, [5] refilling lanes, [6] per-lane group walk, [7] working
+       candidate queues off (part of [2] and [3]) */
     uint64_t clock_ticks[8];
     /* (ray, triangle) pairs of the large groups that went through the full evaluation;
        the others were rejected by the bounding-sphere test (see wrt_set_triangle_reject)
@@ -107,6 +107,8 @@ typedef struct wrt_stats {
     /* (ray, sphere) pairs a hierarchy walk of a sphere group evaluated (zero while sphere groups go
        through the uniform loop, which looks at every pair) */
     uint64_t sphere_evaluations;
+    /* wavefronts the bounce kernel's launches ran, the count behind clock_ticks[0] */
+    uint64_t wavefronts;
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */

@@ -163,8 +163,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
     };
 
-    [[maybe_unused]] long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    [[maybe_unused]] const long long born = WRT_CLOCK();
+    long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (a wavefront's lifetime in shader clock cycles is tallied in every build: two clock reads and two
+    // atomics a wavefront; with the kernel's duration it gives the clock the kernel ran at)
+    const long long born = (long long)__builtin_readcyclecounter();
     while (true) {
         long long since = WRT_CLOCK();
         // ---- (a) segments that have seen every group: shade, scatter or end --
@@ -428,14 +430,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         if (pc.triangle_slots) atomicAdd(&A.stats[STAT_PATHS + 6], pc.triangle_slots);
         if (pc.triangle_exact) atomicAdd(&A.stats[STAT_PATHS + 15], pc.triangle_exact);
         if (pc.sphere_exact) atomicAdd(&A.stats[STAT_PATHS + 16], pc.sphere_exact);
+        ticks[0] = ticks[1] = (long long)__builtin_readcyclecounter() - born;
+        atomicAdd(&A.stats[STAT_PATHS + 17], 1ull);
 #if WRT_TIMING
-        ticks[0] = ticks[1] = WRT_CLOCK() - born;
         ticks[7] = queue.drain_ticks;
-        for (int i = 0; i < 8; ++i) {
+#endif
+        for (int i = 0; i < (WRT_TIMING ? 8 : 2); ++i) {
             if (i == 1) atomicMax(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
             else atomicAdd(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
         }
-#endif
     }
 }
 
@@ -1678,6 +1681,7 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     for (int i = 0; i < 8; ++i) out->clock_ticks[i] = raw[STAT_PATHS + 7 + i];
     out->triangle_evaluations = raw[STAT_PATHS + 15];
     out->sphere_evaluations = raw[STAT_PATHS + 16];
+    out->wavefronts = raw[STAT_PATHS + 17];
     return WRT_OK;
 }
 

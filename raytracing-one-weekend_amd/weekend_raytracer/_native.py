@@ -44,7 +44,7 @@ class WrtStats(ctypes.Structure):
         ("cull_tests", ctypes.c_uint64), ("disk_pairs", ctypes.c_uint64),
         ("sphere_lane_slots", ctypes.c_uint64), ("triangle_lane_slots", ctypes.c_uint64),
         ("clock_ticks", ctypes.c_uint64 * 8), ("triangle_evaluations", ctypes.c_uint64),
-        ("sphere_evaluations", ctypes.c_uint64),
+        ("sphere_evaluations", ctypes.c_uint64), ("wavefronts", ctypes.c_uint64),
     ]
 
 
@@ -365,7 +365,8 @@ class Context:
                     cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs),
                     sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots),
                     clock_ticks=np.array(list(s.clock_ticks), dtype=np.int64),
-                    triangle_evaluations=int(s.triangle_evaluations), sphere_evaluations=int(s.sphere_evaluations))
+                    triangle_evaluations=int(s.triangle_evaluations), sphere_evaluations=int(s.sphere_evaluations),
+                    wavefronts=int(s.wavefronts))
 
 
 _contexts = {}

@@ -35,15 +35,14 @@ def run(name):
     ms, launches = ctx.profile_read()
     st = ctx.stats()
     t = st["clock_ticks"].astype(float)
-    # resident waves: a whole number per SIMD, a little above (sum of lifetimes / longest lifetime)
-    waves = max(1, round(t[0] / t[1] / 0.97 / (ctx.compute_units * 4))) * ctx.compute_units * 4 if st["clock_ticks"][1] else 0
+    waves = st["wavefronts"] // max(1, launches)
     names = ["sum of wave lifetimes", "longest lifetime", "triangle loops", "sphere loops", "shading", "refill",
              "per-lane walk", "queues"]
     print(f"{name}: kernel {ms:.2f} ms in {launches} launch(es), {waves} waves")
-    if t[0] == 0:
-        print("  no clock tallies: library not built with -DWRT_TIMING=1")
+    if t[2:8].sum() == 0:
+        print("  no phase tallies: library not built with -DWRT_TIMING=1")
         return
-    print(f"  mean lifetime / longest = {t[0] / waves / t[1]:.3f}   (ticks per ms = {t[1] / ms:.0f})")
+    print(f"  mean lifetime / longest = {t[0] / max(1, st['wavefronts']) / t[1]:.3f}   (ticks per ms = {t[0] / max(1, st['wavefronts']) / (ms / launches):.0f})")
     for i in (2, 3, 4, 5, 6):
         print(f"  {names[i]:22s} {100 * t[i] / t[0]:6.2f} % of wave time")
     print(f"  unaccounted            {100 * (t[0] - t[2:7].sum()) / t[0]:6.2f} %")
