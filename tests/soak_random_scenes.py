@@ -1,7 +1,8 @@
 """Randomised parity soak on the GPU box: many generated scenes (the generator of
 tests/test_gpu_random_scenes.py with random group counts and sizes), each rendered through the C ABI
 with the loops and with every group of 16 or more primitives walked through its hierarchy, every
-path compared with the CPU oracle.
+path compared with the CPU oracle; and the frame's samples rendered in two or three calls (wrt_render,
+wrt_render_static), whose accumulation image must equal the oracle's sample sums bit for bit.
 
     python tests/soak_random_scenes.py [first_seed] [n_scenes] [seconds]
 
@@ -50,6 +51,25 @@ def one_scene(seed):
             bad += 1
             print(f"MISMATCH seed {seed} hierarchy {hierarchy}: {w}x{h}x{s} b{b} s_begin {s_begin}, groups {n_groups} "
                   f"sizes {sizes}: {100 * same.mean():.3f} % of paths equal", flush=True)
+    # the same samples in two or three calls, through wrt_render and through the entry point that
+    # allocates nothing, must leave the same accumulation image as one call (sample by sample addition)
+    if s >= 2:
+        import torch
+        cuts = sorted(set(int(v) for v in rng.integers(1, s, size=2)))
+        edges = [0] + cuts + [s]
+        frame = main.Frame(objs, hierarchy=0)
+        sums = []
+        for static in (False, True):
+            accum = frame.ctx.zeros((w, h, 3), torch.float32)
+            for a, b2 in zip(edges[:-1], edges[1:]):
+                (frame.ctx.render_static if static else frame.ctx.render)(w, h, s_begin + a, s_begin + b2, b, seed, accum)
+            sums.append(accum.cpu().numpy())
+        frame.ctx.close()
+        for static, got_sum in zip((False, True), sums):
+            if not np.array_equal(got_sum.view(np.uint32), want["sample_sum"].astype(np.single).view(np.uint32)):
+                bad += 1
+                print(f"MISMATCH seed {seed}: samples in calls {edges}{' (static entry point)' if static else ''} "
+                      f"leave another sum than one call", flush=True)
     return bad, w * h * s
 
 
