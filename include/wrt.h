@@ -107,7 +107,8 @@ typedef struct wrt_stats {
     /* (ray, sphere) pairs a hierarchy walk of a sphere group evaluated (zero while sphere groups go
        through the uniform loop, which looks at every pair) */
     uint64_t sphere_evaluations;
-    /* wavefronts the bounce kernel's launches ran, the count behind clock_ticks[0] */
+    /* wavefronts of the bounce kernel's launches whose lifetime was measured, the count behind
+       clock_ticks[0] (a wavefront whose clock reads came out of order is left out of both) */
     uint64_t wavefronts;
 } wrt_stats;
 

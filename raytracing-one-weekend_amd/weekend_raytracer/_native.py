@@ -364,7 +364,7 @@ class Context:
                     sphere_pairs=int(s.sphere_pairs), triangle_pairs=int(s.triangle_pairs),
                     cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs),
                     sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots),
-                    clock_ticks=np.array(list(s.clock_ticks), dtype=np.int64),
+                    clock_ticks=np.array(list(s.clock_ticks), dtype=np.uint64).astype(np.int64),
                     triangle_evaluations=int(s.triangle_evaluations), sphere_evaluations=int(s.sphere_evaluations),
                     wavefronts=int(s.wavefronts))
 
