@@ -431,10 +431,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         if (pc.triangle_exact) atomicAdd(&A.stats[STAT_PATHS + 15], pc.triangle_exact);
         if (pc.sphere_exact) atomicAdd(&A.stats[STAT_PATHS + 16], pc.sphere_exact);
         // (the counter is not guaranteed to run on through every change of the chip's power state: a
-        // lifetime that comes out negative is left out)
+        // lifetime that comes out negative or absurdly long is left out)
         const long long lived = (long long)__builtin_readcyclecounter() - born;
-        ticks[0] = ticks[1] = lived > 0 ? lived : 0;
-        if (lived > 0) atomicAdd(&A.stats[STAT_PATHS + 17], 1ull);
+        const bool sound = lived > 0 && lived < (1ll << 40);          // (2^40 cycles: some eight minutes)
+        ticks[0] = ticks[1] = sound ? lived : 0;
+        if (sound) atomicAdd(&A.stats[STAT_PATHS + 17], 1ull);
 #if WRT_TIMING
         ticks[7] = queue.drain_ticks;
 #endif
