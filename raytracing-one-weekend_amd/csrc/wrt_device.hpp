@@ -865,7 +865,7 @@ __device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_C
     drain_triangle_blocks(S, q, g, first, r, w, best, evaluated);
 }
 
-// ---- optional: a lane walks a triangle group's box hierarchy on its own ------
+// ---- optional: a group's box hierarchy, walked by the wavefront's lanes together ------
 // Not the reference's algorithm (it looks at every pair): an optional mode that evaluates
 // triangle_terms / triangle_exact only for the triangles of the leaves a ray's line comes near,
 // with the same closest hit.  What makes it the same hit:
