@@ -473,6 +473,21 @@ __device__ __forceinline__ void sphere_step(SceneArg S, const SpherePair& s, int
     }
 }
 
+// two steps with one vote: four spheres, one v_max3_f32, one v_max_f32 and one compare (a vote that
+// comes out true is rare enough for the four notes it then costs not to matter)
+__device__ __forceinline__ void sphere_step2(SceneArg S, const SpherePair& s, const SpherePair& s2, int index, int count,
+                                             float thr, const SphereBoundRay& r2, LaneQueue& q, int g, int first,
+                                             const Ray& r, float t_min, float sentinel, Closest& best) {
+    const f32x2 d = sphere_discriminant_bound2(r2, s), e = sphere_discriminant_bound2(r2, s2);
+    if (__ballot(fmaxf(fmaxf(fmaxf(d.x, d.y), e.x), e.y) > thr) != 0ull) {
+        push(q, d.x > thr, index);
+        push(q, d.y > thr && index + 1 < count, index + 1);
+        push(q, e.x > thr && index + 2 < count, index + 2);
+        push(q, e.y > thr && index + 3 < count, index + 3);
+        if (short_of_room(q, 4)) drain_spheres(S, q, g, first, r, t_min, sentinel, best);
+    }
+}
+
 // `records`: the group's sphere pairs, 2 x f32x4 each: (c - g, k) of two spheres;
 // (gx, gy, gz) = g
 __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
@@ -496,13 +511,11 @@ __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* 
         WRT_SCALAR_LOADS_ARRIVED();
         B = fetch_sphere_quad(records + 4);
         WRT_PIN();
-        WRT_STEP(A.a, 2 * j);
-        WRT_STEP(A.b, 2 * j + 2);
+        sphere_step2(S, A.a, A.b, 2 * j, count, thr, r2, q, g, first, r, t_min, sentinel, best);
         WRT_SCALAR_LOADS_ARRIVED();
         A = fetch_sphere_quad(records + 8);
         WRT_PIN();
-        WRT_STEP(B.a, 2 * j + 4);
-        WRT_STEP(B.b, 2 * j + 6);
+        sphere_step2(S, B.a, B.b, 2 * j + 4, count, thr, r2, q, g, first, r, t_min, sentinel, best);
         records += 8;
     }
     WRT_SCALAR_LOADS_ARRIVED();
