@@ -58,6 +58,8 @@ WORKLOADS = {
     "cow_teapot": ("cow_teapot", 3840, 2160, 128, 10, (64, 36, 1),
                    "cow.obj + teapot.obj + sphere field; 128 spp per GPU"),
 }
+# which configuration of BASELINE.json a workload stands for (index into its `configs`, counted from 1)
+BASELINE_CONFIG = {"demo": 1, "cover": 2, "bunny": 3, "cloth": 4, "cow_teapot": 5}
 
 
 def build_scene(kind, aspect):
@@ -163,38 +165,82 @@ def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True, hi
     return out
 
 
-def launch_ranks(n_ranks, argv):
+def launch_ranks(n_ranks, argv, job_timeout=540.0, log_dir=None):
     """Start `n_ranks` copies of this script as the ranks of one job (the environment
-    torch.distributed.run would give them) from a parent that has made no GPU call; relay rank 0's
-    stdout; -> the first non-zero exit status of a rank, else 0."""
+    torch.distributed.run would give them) from a parent that has made no GPU call.
+
+    Every rank is watched while rank 0's stdout is collected: the first rank that exits non-zero ends
+    the job (the others would wait for it in a collective until the backend's timeout), and so does
+    `job_timeout` seconds without all ranks done.  Rank 0's stdout (the one JSON line) is passed on only
+    when every rank succeeded; each rank's stderr goes to `bench_rank<r>.err` under `log_dir` (default:
+    BENCH_LOG_DIR or the system's temporary directory) and the failing rank's last lines are shown.
+    -> the first non-zero exit status of a rank (124 for the time limit), else 0."""
     import socket
     import subprocess
+    import tempfile
+    import threading
+    log_dir = log_dir or os.environ.get("BENCH_LOG_DIR") or tempfile.gettempdir()
+    os.makedirs(log_dir, exist_ok=True)
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    ranks = []
+    ranks, logs = [], []
     for rank in range(n_ranks):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
                    LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        log_path = os.path.join(log_dir, f"bench_rank{rank}.err")
+        log = open(log_path, "wb")
+        logs.append((log_path, log))
         ranks.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    status = 0
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=log))
+    collected = []
+
+    def collect():                                   # rank 0 prints the one JSON line
+        for line in ranks[0].stdout:
+            collected.append(line.decode())
+
+    reader = threading.Thread(target=collect, daemon=True)
+    reader.start()
+    status, failed = 0, None
+    deadline = time.monotonic() + job_timeout
     try:
-        for line in ranks[0].stdout:                 # rank 0 prints the one JSON line
-            sys.stdout.write(line.decode())
-            sys.stdout.flush()
-        for proc in ranks:
-            rc = proc.wait()
-            if rc != 0 and status == 0:
-                status = rc
-                for other in ranks:                  # a failed rank leaves the others waiting in a collective
-                    if other.poll() is None:
-                        other.terminate()
+        while status == 0:
+            codes = [proc.poll() for proc in ranks]
+            for rank, rc in enumerate(codes):
+                if rc not in (None, 0):
+                    status, failed = rc, rank
+                    break
+            if status == 0 and all(rc == 0 for rc in codes):
+                break
+            if status == 0 and time.monotonic() > deadline:
+                status = 124
+                sys.stderr.write(f"bench.py launcher: the job did not finish within {job_timeout:.0f} s\n")
+            if status == 0:
+                time.sleep(0.05)
     finally:
-        for proc in ranks:
+        for proc in ranks:                           # a failed rank leaves the others waiting in a collective
             if proc.poll() is None:
+                proc.terminate()
+        for proc in ranks:
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
                 proc.kill()
-    return status
+                proc.wait()
+        reader.join(timeout=10)
+        for _, log in logs:
+            log.close()
+    if status == 0:
+        sys.stdout.write("".join(collected))
+        sys.stdout.flush()
+        return 0
+    sys.stderr.write("".join(collected))             # whatever rank 0 said is not a result of a failed job
+    for rank, (log_path, _) in enumerate(logs):
+        if failed is None or rank == failed:
+            with open(log_path, "rb") as fh:
+                tail = fh.read()[-3000:].decode(errors="replace")
+            sys.stderr.write(f"--- rank {rank} (exit status {ranks[rank].returncode}), {log_path}:\n{tail}\n")
+    return status if status > 0 else 1               # (a rank killed by a signal has a negative status)
 
 
 def launch_check(world, rank, backend):
@@ -204,6 +250,13 @@ def launch_check(world, rank, backend):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group(backend)
+    hook = os.environ.get("BENCH_FAIL_RANK")                # test hook of the launcher's CPU tests
+    if hook and world > 1:
+        if hook == str(rank):                               # this rank dies once the ranks have met ...
+            os._exit(3)
+        if hook == "hang" and rank == world - 1:            # ... or never comes to the collective
+            time.sleep(3600)
+        dist.barrier()                                      # the others wait for it in a collective
     seen = torch.ones(1, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(seen)
@@ -234,6 +287,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="N > 1: weak = the workload's spp on every GPU; strong = the workload's spp split over the GPUs")
+    ap.add_argument("--job-timeout", type=float, default=540.0,
+                    help="launcher only (python bench.py --gpus N from a plain shell): seconds after which the job is ended")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, count them over the backend and stop (tests the launcher; no rendering)")
     args = ap.parse_args()
@@ -242,7 +297,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # a plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], job_timeout=args.job_timeout))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -279,14 +334,8 @@ def main():
         raise SystemExit(f"--scaling strong: {spp_total} samples per pixel cannot be split over {world} ranks")
 
     def all_reduce_sum(accum):
-        if world == 1:
-            return
-        if backend == "nccl":
-            dist.all_reduce(accum)
-        else:                                       # gloo rehearsal: reduce through the host
-            host = accum.cpu()
-            dist.all_reduce(host)
-            accum.copy_(host)
+        if world > 1:
+            distributed.all_reduce_sum(accum)       # RCCL in place; a gloo rehearsal goes through the host
 
     def render_samples(s_begin, s_end):
         accum = ctx.zeros((width, height, 3), torch.float32)
@@ -339,6 +388,13 @@ def main():
         # direction blows up and a sample's colour leaves [0, 1] (the CPU oracle reproduces those paths bit
         # for bit), so sqrt(mean) can be NaN in a handful of pixels, exactly as numpy.sqrt gives the reference.
         bad_pixels = int((~torch.isfinite(image).all(dim=2)).sum().item())
+        # what was rendered, so that lines from runs with different N can be told to show the same picture:
+        # the image's mean over its finite pixels (equal over N up to the float32 order of the ranks' sums)
+        # and a CRC of its 8-bit form (equal unless a sum lands within that order of a quantisation step)
+        import zlib
+        finite = torch.where(torch.isfinite(image), image, torch.zeros_like(image))
+        image_check = {"mean": round(float(finite.double().mean().item()), 7),
+                       "bytes_crc32": zlib.crc32(ctx.image_bytes(image).cpu().numpy().tobytes())}
         achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         # mean wavefront lifetime in shader clock cycles over the average kernel duration (the wavefronts are
         # resident for the whole launch; the chip's clock domains differ by a few per cent, this is their mean)
@@ -366,6 +422,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            # the configuration of BASELINE.json this line's scene belongs to, and whether the line is that
+            # configuration as stated (size, samples, GPU count: config 5 is 8 GPUs x 128 spp, the others one
+            # GPU) or its scene at another size, sample count or GPU count
+            "baseline_config": BASELINE_CONFIG[args.workload],
+            "baseline_config_exact": not (args.spp or args.width or args.height) and
+            (world == (8 if args.workload == "cow_teapot" else 1)) and (world == 1 or args.scaling == "weak"),
+            "image_check": image_check,
             "config": {
                 "workload": f"{args.workload}: {desc}", "width": width, "height": height,
                 "spp_per_gpu": s_mine[1] - s_mine[0], "spp_total": spp_total, "max_bounces": bounces,

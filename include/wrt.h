@@ -23,7 +23,11 @@
  *     stream than the context's previous one is ordered behind it on the
  *     device, and wrt_scene_commit, wrt_set_texture and wrt_destroy wait on
  *     the host for the context's last launch before they overwrite or free
- *     what it reads;
+ *     what it reads.  A call on a stream that is being captured into a HIP
+ *     graph is left out of that bookkeeping (the context's event is neither
+ *     recorded nor waited for inside the capture): the caller orders the
+ *     graph's replays against wrt_scene_commit, wrt_set_texture and
+ *     wrt_destroy, e.g. by synchronising the replay stream first;
  *   - arithmetic follows the reference operation by operation: float32
  *     intersection without fused multiply-adds, float64 scatter arithmetic
  *     on float32 values, same thresholds and tie-breaks.
@@ -186,7 +190,9 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
    fit the array.  width * height > WRT_STATIC_MAX_PIXELS returns WRT_E_LIMIT.  All contexts of a
    GPU share that GPU's array: calls that overlap on one GPU (two streams, two contexts, two
    threads) race; calls on one stream, or ordered by the caller, do not.  Kernel timing
-   (wrt_profile_enable) does not cover this entry point. */
+   (wrt_profile_enable) does not cover this entry point.  Under stream capture the call records
+   its launches (one memset node and two kernel nodes per batch of samples) and nothing else; a
+   replay reads the scene that is committed when it runs, see the note on captured streams above. */
 int wrt_render_static(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int max_bounces,
                       float t_min, float t_max, uint64_t seed, float* accum, void* stream);
 

@@ -703,7 +703,21 @@ static int bind(wrt_ctx* ctx, DeviceScope& scope) {
 // mark_use: called after the launches of an entry point on `st`.  wait_for_use: host-side wait
 // before any of those is overwritten or freed.  order_after_use: a launch on another stream than
 // the last one waits for it on the device.
+// A stream under capture records a graph instead of running anything.  An event recorded on it
+// becomes part of the capture (a later hipEventSynchronize on it fails), a wait on an event from
+// outside the capture is not allowed, and the replays of the graph are launches this library never
+// sees.  So a call on such a stream leaves the context's event alone: whoever replays the graph
+// orders the replays against wrt_scene_commit, wrt_set_texture and wrt_destroy.
+static int stream_is_capturing(wrt_ctx* ctx, hipStream_t st, bool& capturing) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    HIP_TRY(ctx, hipStreamIsCapturing(st, &status));
+    capturing = status != hipStreamCaptureStatusNone;
+    return WRT_OK;
+}
 static int mark_use(wrt_ctx* ctx, hipStream_t st) {
+    bool capturing = false;
+    if (int r = stream_is_capturing(ctx, st, capturing)) return r;
+    if (capturing) return WRT_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->last_use, st));
     ctx->last_stream = st;
     ctx->used = true;
@@ -715,7 +729,10 @@ static int wait_for_use(wrt_ctx* ctx) {
     return WRT_OK;
 }
 static int order_after_use(wrt_ctx* ctx, hipStream_t st) {
-    if (ctx->used && st != ctx->last_stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_use, 0));
+    if (!ctx->used || st == ctx->last_stream) return WRT_OK;
+    bool capturing = false;
+    if (int r = stream_is_capturing(ctx, st, capturing)) return r;
+    if (!capturing) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_use, 0));
     return WRT_OK;
 }
 
@@ -826,17 +843,19 @@ static int new_group(wrt_ctx* ctx, const GroupRec& g, int* group_id) {
     return WRT_OK;
 }
 
-int wrt_add_sphere_group(wrt_ctx* ctx, const float* centres, const float* radii, const uint8_t* materials,
-                         int count, int* group_id) {
-    WRT_BIND(ctx);
-    if (!centres || !radii || !materials || count <= 0) return fail(ctx, WRT_E_ARG, "wrt_add_sphere_group: bad argument");
+}  // extern "C"
+
+// The host halves of the wrt_add_* entry points: arrays in host memory -> the context's staging
+// vectors.  (Apart from the entry points so that a host-only driver can feed them without a GPU:
+// tests/native/check_host.hip runs them under the address and undefined-behaviour sanitizers.)
+static int sphere_group_fits(wrt_ctx* ctx, int count) {
     if (ctx->h_sph.size() + (size_t)count > (size_t)WRT_MAX_SCENE_PRIMITIVES)
         return fail(ctx, WRT_E_LIMIT, "wrt_add_sphere_group: more than WRT_MAX_SCENE_PRIMITIVES spheres in the scene");
-    std::vector<float> c, rad;
-    std::vector<uint8_t> m;
-    if (int r = fetch(ctx, c, centres, (size_t)count * 3)) return r;
-    if (int r = fetch(ctx, rad, radii, (size_t)count)) return r;
-    if (int r = fetch(ctx, m, materials, (size_t)count)) return r;
+    return WRT_OK;
+}
+static int append_sphere_group(wrt_ctx* ctx, const float* c, const float* rad, const uint8_t* m, int count,
+                               int* group_id) {
+    if (int r = sphere_group_fits(ctx, count)) return r;
     GroupRec g;
     std::memset(&g, 0, sizeof(g));
     g.type = GROUP_SPHERES; g.first = (int)ctx->h_sph.size(); g.count = count; g.material = -1;
@@ -851,13 +870,8 @@ int wrt_add_sphere_group(wrt_ctx* ctx, const float* centres, const float* radii,
     return new_group(ctx, g, group_id);
 }
 
-int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const float* B, const float* n0,
-                           const float* n1, const float* n2, const float* uv0, const float* uv1, const float* uv2,
-                           int count, int material_id, const float bounds_centre[3], float bounds_radius,
-                           int* group_id) {
-    WRT_BIND(ctx);
-    if (!pt0 || !A || !B || !n0 || !n1 || !n2 || !uv0 || !uv1 || !uv2 || !bounds_centre || count <= 0)
-        return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: bad argument");
+// v[0..8]: pt0, A, B, n0, n1, n2 ([count][3]) and uv0, uv1, uv2 ([count][2])
+static int triangle_group_fits(wrt_ctx* ctx, int count, int material_id) {
     if (material_id < 0 || material_id >= WRT_MAX_MATERIALS)
         return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: material index must fit uint8");
     // the loops' queue entries hold a 16-triangle block in 16 bits and pooled items a triangle in 24
@@ -866,10 +880,11 @@ int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const
                                       "in one group: split the mesh into several groups");
     if (ctx->h_tri_bz.size() + (size_t)count > (size_t)WRT_MAX_SCENE_PRIMITIVES)
         return fail(ctx, WRT_E_LIMIT, "wrt_add_triangle_group: more than WRT_MAX_SCENE_PRIMITIVES triangles in the scene");
-    std::vector<float> v[9];
-    const float* src[9] = {pt0, A, B, n0, n1, n2, uv0, uv1, uv2};
-    for (int k = 0; k < 9; ++k)
-        if (int r = fetch(ctx, v[k], src[k], (size_t)count * (k < 6 ? 3 : 2))) return r;
+    return WRT_OK;
+}
+static int append_triangle_group(wrt_ctx* ctx, const float* const v[9], int count, int material_id,
+                                 const float bounds_centre[3], float bounds_radius, int* group_id) {
+    if (int r = triangle_group_fits(ctx, count, material_id)) return r;
     GroupRec g;
     std::memset(&g, 0, sizeof(g));
     g.type = GROUP_TRIANGLES; g.first = (int)(ctx->h_tri.size() / 2); g.count = count; g.material = material_id;
@@ -891,9 +906,42 @@ int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const
     return new_group(ctx, g, group_id);
 }
 
-int wrt_add_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], const float U[3], const float V[3],
-                 double radius, int material_index, int* group_id) {
+extern "C" {
+
+int wrt_add_sphere_group(wrt_ctx* ctx, const float* centres, const float* radii, const uint8_t* materials,
+                         int count, int* group_id) {
     WRT_BIND(ctx);
+    if (!centres || !radii || !materials || count <= 0) return fail(ctx, WRT_E_ARG, "wrt_add_sphere_group: bad argument");
+    if (int r = sphere_group_fits(ctx, count)) return r;        // before anything is read through the pointers
+    std::vector<float> c, rad;
+    std::vector<uint8_t> m;
+    if (int r = fetch(ctx, c, centres, (size_t)count * 3)) return r;
+    if (int r = fetch(ctx, rad, radii, (size_t)count)) return r;
+    if (int r = fetch(ctx, m, materials, (size_t)count)) return r;
+    return append_sphere_group(ctx, c.data(), rad.data(), m.data(), count, group_id);
+}
+
+int wrt_add_triangle_group(wrt_ctx* ctx, const float* pt0, const float* A, const float* B, const float* n0,
+                           const float* n1, const float* n2, const float* uv0, const float* uv1, const float* uv2,
+                           int count, int material_id, const float bounds_centre[3], float bounds_radius,
+                           int* group_id) {
+    WRT_BIND(ctx);
+    if (!pt0 || !A || !B || !n0 || !n1 || !n2 || !uv0 || !uv1 || !uv2 || !bounds_centre || count <= 0)
+        return fail(ctx, WRT_E_ARG, "wrt_add_triangle_group: bad argument");
+    if (int r = triangle_group_fits(ctx, count, material_id)) return r;   // before anything is read through the pointers
+    std::vector<float> v[9];
+    const float* src[9] = {pt0, A, B, n0, n1, n2, uv0, uv1, uv2};
+    for (int k = 0; k < 9; ++k)
+        if (int r = fetch(ctx, v[k], src[k], (size_t)count * (k < 6 ? 3 : 2))) return r;
+    const float* const host[9] = {v[0].data(), v[1].data(), v[2].data(), v[3].data(), v[4].data(),
+                                  v[5].data(), v[6].data(), v[7].data(), v[8].data()};
+    return append_triangle_group(ctx, host, count, material_id, bounds_centre, bounds_radius, group_id);
+}
+
+}  // extern "C"
+
+static int append_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], const float U[3], const float V[3],
+                       double radius, int material_index, int* group_id) {
     if (!centre || !normal || !U || !V || !(radius > 0.0)) return fail(ctx, WRT_E_ARG, "wrt_add_disk: bad argument");
     if (material_index < 0 || material_index >= WRT_MAX_MATERIALS)
         return fail(ctx, WRT_E_ARG, "wrt_add_disk: material index must fit uint8");
@@ -908,6 +956,14 @@ int wrt_add_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], con
     }
     g.c[3] = (float)(radius * radius);            // radius ** 2 as a Python float, compared in float32 (disk.py:27,69)
     return new_group(ctx, g, group_id);
+}
+
+extern "C" {
+
+int wrt_add_disk(wrt_ctx* ctx, const float centre[3], const float normal[3], const float U[3], const float V[3],
+                 double radius, int material_index, int* group_id) {
+    WRT_BIND(ctx);
+    return append_disk(ctx, centre, normal, U, V, radius, material_index, group_id);
 }
 
 int wrt_set_materials(wrt_ctx* ctx, const wrt_material* table, int count) {
@@ -1336,8 +1392,30 @@ static void build_trees(wrt_ctx* ctx) {
     ctx->h_tree.push_back(f32x4{0.0f, 0.0f, 0.0f, 0.0f});
 }
 
-int wrt_scene_commit(wrt_ctx* ctx) {
-    WRT_BIND(ctx);
+}  // extern "C"
+
+// The loops fetch records ahead of their use (see WRT_SCALAR_LOADS_ARRIVED): the sphere loop up to six
+// f32x4 past a group's last pair, the triangle loops one pair record (five, or four of the bounding
+// records) past it.  Those reads land in the next group's records or in the padding that ends each
+// array; this is the check that they do, for every group, whatever its size.
+static bool fetch_margins_hold(const wrt_ctx* ctx) {
+    for (const GroupRec& g : ctx->h_groups) {
+        if (g.type == GROUP_DISK) continue;
+        const size_t pairs = ((size_t)g.count + 1) / 2;
+        const size_t pair_end = (size_t)g.pair_base + (g.type == GROUP_SPHERES ? 2 : 5) * pairs;
+        if (pair_end + (g.type == GROUP_SPHERES ? 6 : 5) > ctx->h_pairs.size()) return false;
+        if (g.type == GROUP_TRIANGLES) {
+            const size_t blocks = ((size_t)g.count + 15) / 16;
+            if ((size_t)g.bound_base + 4 * 8 * blocks + 4 > ctx->h_bounds.size()) return false;
+        }
+    }
+    return true;
+}
+
+// The host half of wrt_scene_commit, first part: the loops' own views of the staged primitives (pair
+// records, bounding records, hierarchies), the slots of the large groups and the numbers of takers
+// their loops wait for.  No GPU call.
+static int pack_scene(wrt_ctx* ctx) {
     for (int i = 0; i < WRT_MAX_MATERIALS; ++i)
         if (ctx->h_materials[i].kind == WRT_MAT_TEXTURED && !ctx->h_textures[ctx->h_materials[i].texture].rgb)
             return fail(ctx, WRT_E_STATE, "a textured material names a texture slot that was never set");
@@ -1427,6 +1505,15 @@ int wrt_scene_commit(wrt_ctx* ctx) {
         }
         ctx->h_slot_table = table;
     }
+    if (!fetch_margins_hold(ctx))
+        return fail(ctx, WRT_E_STATE, "wrt_scene_commit: a group's loop would fetch past the end of its record array");
+    return WRT_OK;
+}
+
+// Second part: the scene blob.  With host == nullptr only the size is computed; otherwise `host`
+// (that many bytes) receives the blob and ctx->scene the addresses its regions will have once the blob
+// lies at `device_base`.
+static int lay_out_blob(wrt_ctx* ctx, unsigned char* device_base, unsigned char* host, size_t& total) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t b_sph = up(ctx->h_sph.size() * sizeof(f32x4) + 16), b_rad = up(ctx->h_sph_radius.size() * 4 + 16),
                  b_smat = up(ctx->h_sph_material.size() + 16), b_tri = up(ctx->h_tri.size() * sizeof(f32x4) + 16),
@@ -1437,23 +1524,18 @@ int wrt_scene_commit(wrt_ctx* ctx) {
                  b_pairs = up(ctx->h_pairs.size() * sizeof(f32x4) + 16),
                  b_bounds = up(ctx->h_bounds.size() * sizeof(f32x4) + 16), b_slots = up(128 * sizeof(int)),
                  b_tree = up(ctx->h_tree.size() * sizeof(f32x4) + 16);
-    const size_t total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs +
+    total = b_sph + b_rad + b_smat + b_tri + b_bz + b_shade + b_grp + b_mat + b_tex + b_cam + b_pairs +
                          b_bounds + b_slots + b_tree;
     // pair_base, bound_base and tree_base are int offsets in f32x4 units
     if (ctx->h_pairs.size() > (size_t)INT32_MAX || ctx->h_bounds.size() > (size_t)INT32_MAX ||
         ctx->h_tree.size() > (size_t)INT32_MAX)
         return fail(ctx, WRT_E_LIMIT, "wrt_scene_commit: the scene's loop records do not fit 32-bit offsets");
-    if (int r = wait_for_use(ctx)) return r;                  // a launch in flight may still read the old blob
-    if (total > ctx->blob_bytes) {
-        if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
-        ctx->blob_bytes = total;
-    }
-    std::vector<unsigned char> host(total, 0);
+    if (!host) return WRT_OK;
+    std::memset(host, 0, total);
     size_t off = 0;
     auto put = [&](const void* src, size_t bytes, size_t reserved) {
-        if (bytes) std::memcpy(host.data() + off, src, bytes);
-        unsigned char* dev = (unsigned char*)ctx->d_blob + off;
+        if (bytes) std::memcpy(host + off, src, bytes);
+        unsigned char* dev = device_base + off;
         off += reserved;
         return dev;
     };
@@ -1474,7 +1556,6 @@ int wrt_scene_commit(wrt_ctx* ctx) {
     S.tree = (const f32x4*)put(ctx->h_tree.data(), ctx->h_tree.size() * sizeof(f32x4), b_tree);
     S.n_slots = (int)ctx->h_slot_group.size();
     S.n_groups = (int)ctx->h_groups.size();
-    HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
     {
         bool triangles = false;
         for (const GroupRec& g : ctx->h_groups) triangles = triangles || g.type == GROUP_TRIANGLES;
@@ -1483,6 +1564,25 @@ int wrt_scene_commit(wrt_ctx* ctx) {
         for (const GroupRec& g : ctx->h_groups)
             if (g.tree_base >= 0 && g.count > ctx->largest_tree_group) ctx->largest_tree_group = g.count;
     }
+    return WRT_OK;
+}
+
+extern "C" {
+
+int wrt_scene_commit(wrt_ctx* ctx) {
+    WRT_BIND(ctx);
+    if (int r = pack_scene(ctx)) return r;
+    size_t total = 0;
+    if (int r = lay_out_blob(ctx, nullptr, nullptr, total)) return r;
+    if (int r = wait_for_use(ctx)) return r;                  // a launch in flight may still read the old blob
+    if (total > ctx->blob_bytes) {
+        if (ctx->d_blob) { HIP_TRY(ctx, hipFree(ctx->d_blob)); ctx->d_blob = nullptr; ctx->blob_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_blob, total));
+        ctx->blob_bytes = total;
+    }
+    std::vector<unsigned char> host(total);
+    if (int r = lay_out_blob(ctx, (unsigned char*)ctx->d_blob, host.data(), total)) return r;
+    HIP_TRY(ctx, hipMemcpy(ctx->d_blob, host.data(), total, hipMemcpyHostToDevice));
     ctx->committed = true;
     return WRT_OK;
 }
@@ -1498,6 +1598,9 @@ static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int
                            int max_bounces, float t_min, float t_max, uint64_t seed, float* accum, float* paths,
                            unsigned long long* next_batch, bool timed, hipStream_t st) {
     const long long n_pixels = (long long)width * height;
+    bool capturing = false;
+    if (int r = stream_is_capturing(ctx, st, capturing)) return r;
+    if (capturing && timed) return fail(ctx, WRT_E_STATE, "kernel timing (wrt_profile_enable) on a stream under capture");
     if (int r = order_after_use(ctx, st)) return r;
     for (int s0 = 0; s0 < n_total; s0 += per_launch) {
         const int ns = (n_total - s0 < per_launch) ? n_total - s0 : per_launch;
@@ -1656,8 +1759,10 @@ int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles) {
 
 int wrt_stats_reset(wrt_ctx* ctx, void* stream) {
     WRT_BIND(ctx);
+    // a render in flight on another stream still adds to the counters
+    if (int r = order_after_use(ctx, (hipStream_t)stream)) return r;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(wrt_stats), (hipStream_t)stream));
-    return WRT_OK;
+    return mark_use(ctx, (hipStream_t)stream);
 }
 
 int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
@@ -1696,6 +1801,7 @@ int wrt_generate_rays(wrt_ctx* ctx, int width, int height, int s_begin, int s_en
     if (width <= 0 || height <= 0 || s_begin < 0 || s_end <= s_begin || !origins || !dirs)
         return fail(ctx, WRT_E_ARG, "wrt_generate_rays: bad argument");
     const long long n = (long long)width * height * (s_end - s_begin);
+    if (int r = order_after_use(ctx, (hipStream_t)stream)) return r;
     hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        ctx->scene, width, height, s_begin, s_end - s_begin, (uint32_t)(seed & 0xffffffffu),
                        (uint32_t)(seed >> 32), origins, dirs);
@@ -1712,6 +1818,7 @@ int wrt_intersect(wrt_ctx* ctx, int group, const float* origins, const float* di
     if (n == 0) return WRT_OK;
     if (!origins || !dirs || n < 0) return fail(ctx, WRT_E_ARG, "wrt_intersect: bad argument");
     IntersectOut O = {hit, t, p, normal, uv, material, back, hit_group, prim};
+    if (int r = order_after_use(ctx, (hipStream_t)stream)) return r;
     hipLaunchKernelGGL(k_intersect, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
                        group, origins, dirs, (long long)n, t_min, t_max, O);
     HIP_TRY(ctx, hipGetLastError());
@@ -1731,6 +1838,7 @@ int wrt_scatter(wrt_ctx* ctx, int material_index, const float* dirs, const float
     if (!dirs || !points || !normals || !uvs || !back || !px || !py || !ps || !out_dirs || !out_colours || !absorbed ||
         n < 0 || bounce < 0 || bounce > 255)
         return fail(ctx, WRT_E_ARG, "wrt_scatter: bad argument");
+    if (int r = order_after_use(ctx, (hipStream_t)stream)) return r;
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->scene,
                        material_index, dirs, points, normals, uvs, back, px, py, ps, bounce,
                        (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (long long)n, out_dirs, out_colours,

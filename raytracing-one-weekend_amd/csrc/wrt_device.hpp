@@ -1396,10 +1396,15 @@ __device__ __forceinline__ bool odd_cell(double value) {
     return (f - 2.0 * floor(f * 0.5)) != 0.0;
 }
 
-// x ** 5 as numpy evaluates it for a float64 array (materials.py:369): pow(x, 5.0), which the C
-// library rounds correctly but for a vanishing share of arguments.  The product is carried in
-// two doubles (error-free products through fma) and rounded once.
-__device__ __forceinline__ double fifth_power(double x) {
+// x ** 5 as numpy evaluates it for a float64 array (materials.py:369): pow(x, 5.0) of the C library
+// numpy is built against.  Here the product is carried in two doubles (error-free products through
+// fma, relative error below 2^-100) and rounded once: the correctly rounded fifth power.  The C
+// library's pow is not correctly rounded for every argument (glibc documents an error below 0.52 ulp;
+// tests/test_fifth_power.py counts the arguments on which it differs from this function, by one
+// unit in the last place), and a last-place difference of the reflectance changes a path only if the
+// path's uniform draw falls between the two values, a chance of about 2^-52 per refracting hit.
+// (__host__ as well, so that the test can run the function itself on the CPU.)
+__host__ __device__ __forceinline__ double fifth_power(double x) {
     const double h2 = x * x, l2 = __builtin_fma(x, x, -h2);
     const double h4 = h2 * h2, l4 = __builtin_fma(h2, h2, -h4) + 2.0 * (h2 * l2);
     const double h5 = h4 * x, l5 = __builtin_fma(h4, x, -h5) + l4 * x;

@@ -141,7 +141,6 @@ class Context:
         if rc != 0:
             raise NativeError(f"wrt_create: {self.lib.wrt_last_error(None).decode()}")
         self.handle = handle
-        self.scene_token = None
         preset = int(os.environ.get("WRT_HIERARCHY", "0"))     # see main.HIERARCHY
         if preset:
             self.set_hierarchy(preset)
@@ -247,7 +246,6 @@ class Context:
             a, b = _f32(sky["horizon"]), _f32(sky["zenith"])
             self.check(lib.wrt_set_sky(h, _hostptr(a), _hostptr(b)), "wrt_set_sky")
         self.check(lib.wrt_scene_commit(h), "wrt_scene_commit")
-        self.scene_token = None
 
     # ---- device helpers ------------------------------------------------
     def to_device(self, a, dtype):
@@ -385,8 +383,12 @@ def context(device=None):
 
 def _content_token(value):
     """A digest of everything a flat scene holds (nested dicts / lists of arrays and scalars)."""
-    import hashlib
-    h = hashlib.blake2b(digest_size=16)
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()                      # several GB/s: a texture or a mesh costs a fraction of a millisecond
+    except ImportError:
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
 
     def feed(v):
         if isinstance(v, dict):
@@ -402,19 +404,53 @@ def _content_token(value):
         else:
             a = np.ascontiguousarray(v)
             h.update(str(a.dtype).encode() + str(a.shape).encode())
-            h.update(a.tobytes())
+            h.update(a.data if a.size else b"")
     feed(value)
     return h.digest()
 
 
-def use_scene(ctx, owner, flat_fn):
-    """Upload owner's flat scene into ctx unless exactly that content is already there.
+# The per-object interface (group.get_hits, material.scatter, camera.get_ray_components) keeps what it
+# has uploaded resident: a few contexts per GPU and kind of object, least recently used first out, each
+# holding one object's flat scene under the digest of its content.  The loop of reference
+# main.py:124-200 calls every group and every material once per bounce; with one shared context each of
+# those calls would upload its object again (host packing, hipMemcpy, a tree build when the hierarchy
+# is on), bounce after bounce.
+RESIDENT_CAPACITY = {"groups": 8, "materials": 24, "camera": 2}
+_resident = {}
+upload_count = 0            # uploads the per-object interface has made in this process
+
+
+def resident_scene(kind, flat_fn, device=None):
+    """-> a context of `device` that holds exactly flat_fn()'s content, uploading it only if no context
+    of that kind holds it already.
 
     The reference's objects are mutable builders (sphere_group.py:25, camera.py:13, any attribute may
     be assigned between calls), so what decides is the content handed to the GPU, not the identity of
-    the object: a digest of the flat scene is compared with the one of the last upload."""
+    the object: the digest of the flat scene is the key."""
+    global upload_count
+    from collections import OrderedDict
+    torch = _torch()
+    device = int(torch.cuda.current_device() if device is None else device)
+    held = _resident.setdefault((device, kind), OrderedDict())
     flat = flat_fn()
     token = _content_token(flat)
-    if ctx.scene_token != token:
-        ctx.upload(flat)
-        ctx.scene_token = token
+    ctx = held.get(token)
+    if ctx is not None:
+        held.move_to_end(token)
+        return ctx
+    if len(held) >= RESIDENT_CAPACITY[kind]:
+        _, ctx = held.popitem(last=False)          # the least recently used context takes the new content
+    else:
+        ctx = Context(device)
+    ctx.upload(flat)
+    upload_count += 1
+    held[token] = ctx
+    return ctx
+
+
+def release_resident():
+    """Close every context the per-object interface holds."""
+    for held in _resident.values():
+        for ctx in held.values():
+            ctx.close()
+    _resident.clear()

@@ -46,8 +46,7 @@ class Camera():
 
     def get_ray_components(self, width, height, samples):
         """-> (origins, dirs), float32 arrays of shape (width, height, samples, 3)."""
-        ctx = _native.context()
-        _native.use_scene(ctx, self, lambda: dict(camera=self._flat()))
+        ctx = _native.resident_scene("camera", lambda: dict(camera=self._flat()))
         o, d = ctx.generate_rays(width, height, S_BEGIN, S_BEGIN + samples, SEED)
         shape = (width, height, samples, 3)
         return o.cpu().numpy().reshape(shape), d.cpu().numpy().reshape(shape)

@@ -32,7 +32,6 @@ class Disk():
         """-> (hits, ts, hit_pts, hit_normals, hit_uvs, hit_material_indecies, back_facing).
         Entries of rays without a hit are zero (t = t_max + 1); the reference
         leaves unmasked intermediate values there, which main.render() never reads."""
-        ctx = _native.context()
-        _native.use_scene(ctx, self, lambda: dict(groups=[self._flat()]))
+        ctx = _native.resident_scene("groups", lambda: dict(groups=[self._flat()]))
         r = ctx.intersect(0, ray_origins, ray_dirs, t_min, t_max)
         return r["hit"], r["t"], r["p"], r["n"], r["uv"], r["mat"], r["back"]

@@ -28,6 +28,21 @@ def accumulate_sharded(render_samples, total_samples, rank, world_size, all_redu
     return accum
 
 
+def all_reduce_sum(accum, group=None):
+    """Sum a CUDA accumulation image over the ranks of the process group, in place.  With the
+    "nccl" backend (RCCL on ROCm) the tensor is reduced where it lies, over xGMI; a host-side
+    backend (gloo: several ranks sharing one GPU, rehearsals without RCCL) goes through host memory."""
+    import torch.distributed as dist
+    if dist.get_world_size(group) == 1:
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+    else:
+        host = accum.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        accum.copy_(host)
+
+
 def render_distributed(frame, width, height, total_samples, max_bounces, seed, group=None):
     """Render with every rank of the default (or given) torch.distributed
     process group; -> (image CUDA tensor on every rank, accum)."""
@@ -41,6 +56,5 @@ def render_distributed(frame, width, height, total_samples, max_bounces, seed, g
             frame.accumulate(width, height, s_begin, s_end, max_bounces, seed, accum=accum)
         return accum
 
-    accum = accumulate_sharded(render_samples, total_samples, rank, world,
-                               lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group))
+    accum = accumulate_sharded(render_samples, total_samples, rank, world, lambda t: all_reduce_sum(t, group))
     return frame.image(accum, total_samples), accum

@@ -34,8 +34,7 @@ def _scatter(material, hit_raydirs, hit_points, hit_normals, hit_uvs, hit_backfa
     if n == 0:
         return (hit_points, numpy.zeros((0, 3), dtype=numpy.single), numpy.zeros((0, 3), dtype=numpy.single),
                 numpy.zeros((0,), dtype=bool))
-    ctx = _native.context()
-    _native.use_scene(ctx, material, lambda: dict(materials={0: material._flat()}))
+    ctx = _native.resident_scene("materials", lambda: dict(materials={0: material._flat()}))
     dirs, cols, absorbed = ctx.scatter(0, hit_raydirs, hit_points, hit_normals, hit_uvs, hit_backfaces,
                                        px, py, ps, st["bounce"], st["seed"])
     return hit_points, dirs, cols, absorbed

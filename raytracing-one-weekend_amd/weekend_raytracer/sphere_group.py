@@ -57,7 +57,6 @@ class SphereGroup():
     def get_hits(self, ray_origins, ray_dirs, t_min, t_max):
         """-> (ray_hits, hit_ts, hit_pts, hit_normals, hit_uvs, hit_material_indecies, back_facing).
         Rays without a hit carry zeros, t = t_max + 1 and material 255."""
-        ctx = _native.context()
-        _native.use_scene(ctx, self, lambda: dict(groups=[self._flat()]))
+        ctx = _native.resident_scene("groups", lambda: dict(groups=[self._flat()]))
         r = ctx.intersect(0, ray_origins, ray_dirs, t_min, t_max)
         return r["hit"], r["t"], r["p"], r["n"], r["uv"], r["mat"], r["back"]

@@ -84,7 +84,6 @@ class TriangleGroup():
         """-> (ray_hits, hit_ts, hit_pts, hit_normals, hit_uvs, hit_material_indecies, back_facing).
         Rays without a hit carry zeros and t = t_max + 1; hit_ts is float64
         holding float32 values, like the reference's (triangle_group.py:172)."""
-        ctx = _native.context()
-        _native.use_scene(ctx, self, lambda: dict(groups=[self._flat()]))
+        ctx = _native.resident_scene("groups", lambda: dict(groups=[self._flat()]))
         r = ctx.intersect(0, ray_origins, ray_dirs, t_min, t_max)
         return r["hit"], r["t"].astype(numpy.double), r["p"], r["n"], r["uv"], r["mat"], r["back"]

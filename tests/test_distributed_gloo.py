@@ -89,3 +89,35 @@ def test_bench_launcher_reports_a_failed_rank():
                          env=env, capture_output=True, text=True, timeout=240)
     assert run.returncode != 0
     assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_ends_the_job_when_one_rank_dies(tmp_path):
+    """Rank 1 exits with status 3 after init_process_group while rank 0 waits in a barrier: the parent
+    must notice at once (not after the backend's timeout), end rank 0, return non-zero, print no JSON
+    line and leave rank 1's stderr log where it says."""
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_FAIL_RANK="1", BENCH_LOG_DIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    began = time.monotonic()
+    run = subprocess.run([sys.executable, os.path.join(helpers.REPO, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert time.monotonic() - began < 30.0
+    assert run.returncode == 3, (run.returncode, run.stderr[-2000:])
+    assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert (tmp_path / "bench_rank1.err").exists() and "rank 1 (exit status 3)" in run.stderr
+
+
+def test_bench_launcher_time_limit(tmp_path):
+    """A job that does not finish is ended at --job-timeout with status 124."""
+    import subprocess
+    import sys
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_FAIL_RANK="hang", BENCH_LOG_DIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(helpers.REPO, "bench.py"), "--gpus", "2", "--launch-check",
+                          "--job-timeout", "8"], env=env, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 124 and "did not finish within 8 s" in run.stderr
+    assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]

@@ -61,3 +61,42 @@ def test_bench_two_ranks_from_a_plain_shell(scaling):
     assert out["config"]["spp_total"] == (20 if scaling == "weak" else 10)
     assert out["config"]["spp_per_gpu"] == (10 if scaling == "weak" else 5)
     assert out["value"] > 0 and out["roofline"]["kernel_ms_avg"] > 0
+    assert out["baseline_config"] == 1 and out["baseline_config_exact"] is False
+    assert out["image_check"]["bytes_crc32"] > 0 and 0.0 < out["image_check"]["mean"] < 1.0
+
+
+def test_two_rank_image_equals_the_one_rank_image(tmp_path):
+    """Two ranks (sharing the GPU, gloo) run the product routine - distributed.accumulate_sharded over
+    Frame.accumulate, what bench.py's step runs - on the demo frame, 10 samples split 5 + 5: each rank's
+    own sum is bit for bit the single-process render of its span of sample indices (the sample axis of
+    reference main.py:96-104), the all-reduced image is on both ranks and equals the one-rank image up
+    to the float32 order of the two partial sums, and its sqrt(mean) (main.py:219-220) likewise."""
+    import torch
+    from weekend_raytracer import main, scenes
+    f = helpers.golden("frame_demo")
+    w, h, s, b, _ = (int(v) for v in f["size"])
+    assert s == 10
+    port = free_port()
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    worker = os.path.join(helpers.REPO, "tests", "rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path), "frame_demo", str(s)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        frame = main.Frame(scenes.numpy_one_weekend_demo_scene(w / h))
+    seed = int(f["seed"])
+    for r, (lo, hi) in enumerate(((0, 5), (5, 10))):
+        assert tuple(ranks[r]["span"]) == (lo, hi)
+        alone = frame.accumulate(w, h, lo, hi, b, seed)
+        torch.cuda.synchronize()
+        assert np.array_equal(ranks[r]["own"], alone.cpu().numpy()), r          # bit for bit
+    assert np.array_equal(ranks[0]["accum"], ranks[1]["accum"])                   # every rank holds the sum
+    assert np.array_equal(ranks[0]["accum"], ranks[0]["own"] + ranks[1]["own"])
+    # one rank adds sample after sample; two ranks add two partial sums: float32 order only
+    assert np.allclose(ranks[0]["accum"], f["sample_sum"], rtol=1e-6, atol=0.0)
+    assert np.allclose(ranks[0]["image"], f["image"], rtol=1e-6, atol=0.0)
+    frame.ctx.close()

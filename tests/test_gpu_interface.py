@@ -90,10 +90,16 @@ def scene_objects(name, aspect):
 
 @pytest.mark.parametrize("name", ["demo", "demo_shard", "bunny_textured", "disks"])
 def test_per_object_interface_reproduces_reference_frames(name):
+    from weekend_raytracer import _native
     f = helpers.golden("frame_" + name)
     w, h, s, b, s_begin = (int(v) for v in f["size"])
     trace = []
-    got = per_object_bounce_loop(scene_objects(name, w / h), w, h, s, b, int(f["seed"]), s_begin, trace)
+    scene = scene_objects(name, w / h)
+    _native.release_resident()
+    uploads_before = _native.upload_count
+    got = per_object_bounce_loop(scene, w, h, s, b, int(f["seed"]), s_begin, trace)
+    # every group, every material and the camera go to the GPU once per frame, not once per bounce
+    assert _native.upload_count - uploads_before <= len(scene[1]) + len(scene[2]) + 1
     same = np.all(got["path_colours"] == f["path_colours"], axis=1)
     assert same.all(), (name, same.mean())
     assert np.array_equal(got["segments"], f["segments"])
@@ -236,6 +242,45 @@ def test_calls_leave_the_callers_device_alone():
     torch.cuda.synchronize()
     assert np.array_equal(accum.cpu().numpy(), again.cpu().numpy()) and accum.cpu().numpy().any()
     assert torch.cuda.current_device() == before
+    ctx.close()
+
+
+def test_stage_call_on_another_stream_keeps_a_running_render_ordered():
+    """A render in flight on a side stream, then a stage call (get_hits) on the current stream, then a
+    scene upload: the upload has to wait for the render too, not only for the stage call that
+    came last, or the render would read a scene that changes under it."""
+    import torch
+    from weekend_raytracer import _native
+    demo = helpers.golden_scene(helpers.golden("frame_demo"))
+    disks = helpers.golden_scene(helpers.golden("frame_disks"))
+    ctx = _native.Context(0)
+    ctx.upload(demo)
+    w, h, s, b, seed = 1280, 720, 24, 8, 11                    # some tens of milliseconds of rendering
+    want = ctx.zeros((w, h, 3), torch.float32)
+    ctx.render(w, h, 0, s, b, seed, want)
+    torch.cuda.synchronize()
+    rays_o = np.zeros((64, 3), dtype=np.single)
+    rays_d = np.tile(np.array([[0.0, 0.0, -1.0]], dtype=np.single), (64, 1))
+    for stage in ("intersect", "scatter", "generate_rays", "stats_reset"):
+        ctx.upload(demo)
+        got = ctx.zeros((w, h, 3), torch.float32)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ctx.render(w, h, 0, s, b, seed, got)
+        if stage == "intersect":
+            ctx.intersect(-1, rays_o, rays_d, 0.001, 1000.0)
+        elif stage == "scatter":
+            n = 64
+            ctx.scatter(min(demo["materials"]), rays_d, rays_o, -rays_d, np.zeros((n, 2)), np.zeros(n, bool), np.arange(n), np.zeros(n, int),
+                        np.zeros(n, int), 0, seed)
+        elif stage == "generate_rays":
+            ctx.generate_rays(8, 4, 0, 1, seed)
+        else:
+            ctx.stats_reset()
+        ctx.upload(disks)                                       # must not overwrite the scene under the render
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want.cpu().numpy()), stage
     ctx.close()
 
 

@@ -123,3 +123,40 @@ def test_whole_frame(name):
                 assert np.array_equal(rec["rec"][k], f[f"trace_b{bn}_{k}"]), (bn, k)
             for k in ("out_o", "out_d", "colour", "absorbed"):
                 assert np.array_equal(rec[k], f[f"trace_b{bn}_{k}"]), (bn, k)
+
+
+def test_unit_sphere_candidates_are_statistically_the_references_draw():
+    """The keyed unit-sphere candidates lie on a 21-bit lattice, -1 + v * 2**-20, where the reference
+    draws a float64 uniform of [-1, 1) and casts it to float32 (materials.py:407-408).  The lattice's
+    distribution must be the same up to its resolution: acceptance rate of the rejection test
+    (materials.py:417-420: pi / 6), first and second moments of the accepted and normalised
+    directions, against numpy's own draw of the same size (differences within sampling noise), and the
+    lattice's asymmetry, a mean of -2**-21 per coordinate, far below it."""
+    from oracle import keyed_rng
+    n = 1_000_000
+    ids = np.arange(n)
+    x, y, s = ids % 1024, (ids // 1024) % 1024, ids // (1024 * 1024)
+    ours = np.concatenate([keyed_rng.unit_candidate(99, x, y, s, 3, attempt).astype(np.single) for attempt in (0, 1)])
+    theirs = np.random.default_rng(99).uniform(-1.0, 1.0, size=ours.shape).astype(np.single)
+    # every value is on the lattice and exact in float32
+    assert np.all((ours.astype(np.float64) + 1.0) * 1048576.0 % 1.0 == 0.0)
+    assert ours.min() >= -1.0 and ours.max() <= 1.0 - 2.0 ** -20
+    m = ours.shape[0]
+    noise = 4.0 / np.sqrt(m)                                     # four standard errors of a mean of values of [-1, 1]
+
+    def summary(c):
+        len2 = np.einsum("ij,ij->i", c, c)
+        ok = ~np.logical_or(len2 > 1.0, len2 < 0.00001)
+        unit = c[ok] / np.sqrt(len2[ok])[:, None]
+        return ok.mean(), c.mean(axis=0), (c.astype(np.float64) ** 2).mean(axis=0), unit.mean(axis=0), \
+            (unit[:, :, None].astype(np.float64) * unit[:, None, :]).mean(axis=0)
+
+    a_ok, a_mean, a_sq, a_dir, a_cov = summary(ours)
+    b_ok, b_mean, b_sq, b_dir, b_cov = summary(theirs)
+    assert abs(a_ok - np.pi / 6.0) < noise and abs(a_ok - b_ok) < 2 * noise
+    assert np.all(np.abs(a_mean) < noise) and np.all(np.abs(a_sq - 1.0 / 3.0) < noise)
+    assert np.all(np.abs(a_dir) < 2 * noise) and np.all(np.abs(a_dir - b_dir) < 3 * noise)
+    assert np.all(np.abs(a_cov - np.eye(3) / 3.0) < 2 * noise) and np.all(np.abs(a_cov - b_cov) < 3 * noise)
+    # the two candidates of one generator call are not correlated with each other
+    even, odd = ours[:n].astype(np.float64), ours[n:].astype(np.float64)
+    assert np.all(np.abs((even[:, :, None] * odd[:, None, :]).mean(axis=0)) < noise)
