@@ -67,15 +67,14 @@ def test_bench_two_ranks_from_a_plain_shell(scaling):
 
 def test_two_rank_image_equals_the_one_rank_image(tmp_path):
     """Two ranks (sharing the GPU, gloo) run the product routine - distributed.accumulate_sharded over
-    Frame.accumulate, what bench.py's step runs - on the demo frame, 10 samples split 5 + 5: each rank's
+    Frame.accumulate, what bench.py's step runs - on the demo frame, its samples split in halves: each rank's
     own sum is bit for bit the single-process render of its span of sample indices (the sample axis of
     reference main.py:96-104), the all-reduced image is on both ranks and equals the one-rank image up
     to the float32 order of the two partial sums, and its sqrt(mean) (main.py:219-220) likewise."""
     import torch
-    from weekend_raytracer import main, scenes
+    from weekend_raytracer import distributed, main, scenes
     f = helpers.golden("frame_demo")
     w, h, s, b, _ = (int(v) for v in f["size"])
-    assert s == 10
     port = free_port()
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
@@ -89,7 +88,8 @@ def test_two_rank_image_equals_the_one_rank_image(tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         frame = main.Frame(scenes.numpy_one_weekend_demo_scene(w / h))
     seed = int(f["seed"])
-    for r, (lo, hi) in enumerate(((0, 5), (5, 10))):
+    for r, (lo, hi) in enumerate(distributed.shard_samples(s, r, 2) for r in range(2)):
+        assert hi > lo
         assert tuple(ranks[r]["span"]) == (lo, hi)
         alone = frame.accumulate(w, h, lo, hi, b, seed)
         torch.cuda.synchronize()
