@@ -11,7 +11,7 @@ main.py:23) whose consumption order depends on batch composition.  To make
 "identical injected random streams" well defined, every draw is re-keyed by
 what it is used for:
 
-    Philox-4x32-10( counter = (x, y, sample, slot), key = (seed_lo, seed_hi) )
+    Philox-4x32-7( counter = (x, y, sample, slot), key = (seed_lo, seed_hi) )
     slot = purpose | bounce << 4 | call << 12
 
 where (x, y) is the pixel, sample the global sample index of the path, bounce
@@ -51,8 +51,13 @@ _MASK = np.uint64(0xFFFFFFFF)
 _SH = np.uint64(32)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox-4x32-10.  Counter words are array-likes of equal
+# Rounds of the keyed streams: seven, the fewest with which Philox-4x32 passes BigCrush (Salmon et al.,
+# SC'11; ten is Random123's default).  The device generator uses the same number.
+ROUNDS = 7
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=ROUNDS):
+    """Vectorised Philox-4x32 with `rounds` rounds.  Counter words are array-likes of equal
     (broadcastable) shape holding values < 2**32; key words are Python ints.
     Returns four uint32 arrays."""
     c0, c1, c2, c3 = np.broadcast_arrays(
@@ -60,7 +65,7 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     )
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = _M0 * c0
         p1 = _M1 * c2
         hi0, lo0 = p0 >> _SH, p0 & _MASK
@@ -87,7 +92,7 @@ def slot(purpose, bounce, attempt):
 def keyed_words(seed, x, y, sample, purpose, bounce, attempt):
     """The four 32-bit words of the block keyed by the arguments."""
     seed = int(seed)
-    return philox4x32_10(
+    return philox4x32(
         x, y, sample, slot(purpose, bounce, attempt),
         seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF,
     )

@@ -22,8 +22,30 @@ struct RenderArgs {
     unsigned long long* stats;    // wrt_stats layout
     unsigned long long* next_batch;   // work counter of this launch, zero at launch
     int tiles_x, tiles_y;
-    long long n_batches;          // 8x8-pixel tile x sample batches of 64 paths
+    long long n_batches;          // 8x8-pixel tile x sample batches of 64 paths (below 2^32)
+    // division of a batch number by n_samples and of a tile number by tiles_x without a divide (see magic_divide)
+    uint32_t samples_magic, samples_shift, tiles_x_magic, tiles_x_shift;
 };
+
+// n / d for any 32-bit n by one high multiply, a subtraction, an addition and two shifts, d fixed:
+// magic = floor(2^32 (2^l - d) / d) + 1 with l = ceil(log2 d), shift = l (Granlund and Montgomery, "Division
+// by invariant integers using multiplication", figure 4.1).  The software 64-bit division it replaces
+// costs a wavefront some eighty instructions, three of them for every batch of 64 paths.
+__host__ __device__ inline uint32_t magic_divide(uint32_t n, uint32_t magic, uint32_t shift) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(magic, n);
+#else
+    const uint32_t t = (uint32_t)(((unsigned long long)magic * n) >> 32);
+#endif
+    const uint32_t s1 = shift < 1u ? shift : 1u, s2 = shift - s1;
+    return (t + ((n - t) >> s1)) >> s2;
+}
+static void magic_for(uint32_t d, uint32_t& magic, uint32_t& shift) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    magic = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+    shift = l;
+}
 
 #ifndef WRT_RENDER_BLOCK
 #define WRT_RENDER_BLOCK 256
@@ -133,6 +155,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
     const unsigned lane = threadIdx.x & 63u;
     LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0, share_list[TRIANGLES ? threadIdx.x >> 6 : 0],
                        share_best[TRIANGLES ? threadIdx.x >> 6 : 0], 0};
+#if defined(WRT_DRAIN_COUNT)
+    queue.count_trips = queue.count_items = queue.count_rounds = queue.count_longest = 0;
+#endif
     float (*my_batch_rays)[64] = batch_rays[threadIdx.x >> 6];
     // the batch this wave is handing out to its lanes and how many of its 64 paths are gone
     long long batch = 0;
@@ -170,25 +195,37 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
     while (true) {
         long long since = WRT_CLOCK();
         // ---- (a) segments that have seen every group: shade, scatter or end --
-        if (state == LANE_ADVANCE && g == n_groups && pending == 0u) {
+        const bool shading = state == LANE_ADVANCE && g == n_groups && pending == 0u;
+        if (__ballot(shading) != 0ull) {
             const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
             SceneArg S = L.S;
             const WRT_CONST RenderArgs& A = L.A;
-            bool done;
-            if (best.t < t_max) {
-                HitRecord h;
-                shade_record<TRIANGLES>(S, best, ray, h);
-                const MaterialRec& M = S.materials[h.material];
-                done = false;
-                if (M.kind != WRT_MAT_NONE) {
+            const bool hit = shading && best.t < t_max;
+            // The random unit vectors of all the wavefront's hits that take one are drawn together, and
+            // before the hit records are made: all the draw needs to know is the material's kind, and
+            // the fewer numbers are alive across it the better.
+            int material = 0;
+            if (hit) {
+                const GroupRec& G = S.groups[best.group];
+                material = G.type == GROUP_SPHERES ? (int)S.sph_material[best.prim] : G.material;
+            }
+            const MaterialRec& M = S.materials[material];
+            const int kind = hit ? M.kind : WRT_MAT_NONE;
+            float vx, vy, vz;
+            wave_unit_vectors(key, (uint32_t)bounce, hit && draws_unit_vector(kind, M.fuzzy), vx, vy, vz);
+            HitRecord h;
+            if (hit) shade_record<TRIANGLES>(S, best, ray, h);
+            bool done = false;
+            if (hit) {
+                if (kind != WRT_MAT_NONE) {
                     Scattered sc;
-                    scatter_one(S, M, key, (uint32_t)bounce, ray.dx, ray.dy, ray.dz, h, sc);
+                    scatter_one(S, M, key, (uint32_t)bounce, ray.dx, ray.dy, ray.dz, h, vx, vy, vz, sc);
                     ray.ox = h.p[0]; ray.oy = h.p[1]; ray.oz = h.p[2];
                     ray.dx = sc.d[0]; ray.dy = sc.d[1]; ray.dz = sc.d[2];
                     cr *= sc.col[0]; cg *= sc.col[1]; cb *= sc.col[2];
                     done = sc.absorbed;
                 }
-            } else {
+            } else if (shading) {
                 // sky, main.py:206-207
                 const float ts = (ray.dy + 1.0f) * 0.5f;
                 cr *= (1.0f - ts) * S.horizon[0] + ts * S.zenith[0];
@@ -196,19 +233,21 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                 cb *= (1.0f - ts) * S.horizon[2] + ts * S.zenith[2];
                 done = true;
             }
-            ++bounce;
-            int mark = bounce;
-            if (!done && bounce == A.max_bounces) {   // still alive at the limit: main.py:212
-                cr = cg = cb = 0.0f;
-                mark += SURVIVOR_MARK;
-                done = true;
-            }
-            if (done) {
-                f32x4 rec = {cr, cg, cb, (float)mark};
-                reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
-                state = LANE_DEAD;
-            } else {
-                g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
+            if (shading) {
+                ++bounce;
+                int mark = bounce;
+                if (!done && bounce == A.max_bounces) {   // still alive at the limit: main.py:212
+                    cr = cg = cb = 0.0f;
+                    mark += SURVIVOR_MARK;
+                    done = true;
+                }
+                if (done) {
+                    f32x4 rec = {cr, cg, cb, (float)mark};
+                    reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
+                    state = LANE_DEAD;
+                } else {
+                    g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
+                }
             }
         }
         WRT_TALLY(4, since); since = WRT_CLOCK();
@@ -230,10 +269,12 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                 if (batch >= A.n_batches) { drained = true; break; }
                 batch_used = 0;
                 {
-                    const long long tile = batch / A.n_samples;
-                    batch_x0 = (int)(tile % A.tiles_x) * 8;
-                    batch_y0 = (int)(tile / A.tiles_x) * 8;
-                    batch_sample = A.s_begin + (int)(batch - tile * A.n_samples);
+                    const uint32_t number = (uint32_t)batch;                      // n_batches < 2^32
+                    const uint32_t tile = magic_divide(number, A.samples_magic, A.samples_shift);
+                    const uint32_t row = magic_divide(tile, A.tiles_x_magic, A.tiles_x_shift);
+                    batch_x0 = (int)(tile - row * (uint32_t)A.tiles_x) * 8;
+                    batch_y0 = (int)row * 8;
+                    batch_sample = A.s_begin + (int)(number - tile * (uint32_t)A.n_samples);
                 }
                 if (A.max_bounces != 0) {
                     // every lane makes one ray of the batch, whatever path it carries itself
@@ -439,7 +480,17 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
 #if WRT_TIMING
         ticks[7] = queue.drain_ticks;
 #endif
-        for (int i = 0; i < (WRT_TIMING ? 8 : 2); ++i) {
+#if defined(WRT_DRAIN_COUNT)
+        // measurement build: pooled drains, expansion trips, items, evaluation rounds, longest lists (summed)
+        ticks[2] = queue.drain_ticks; ticks[3] = queue.count_trips; ticks[4] = queue.count_items;
+        ticks[5] = queue.count_rounds; ticks[6] = queue.count_longest;
+#endif
+#if WRT_TIMING || defined(WRT_DRAIN_COUNT)
+        const int tallies = 8;
+#else
+        const int tallies = 2;
+#endif
+        for (int i = 0; i < tallies; ++i) {
             if (i == 1) atomicMax(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
             else atomicAdd(&A.stats[STAT_PATHS + 7 + i], (unsigned long long)ticks[i]);
         }
@@ -574,8 +625,10 @@ __global__ __launch_bounds__(256) void k_scatter(const SceneRec, int material_in
                                                  long long n, float* __restrict__ out_dirs,
                                                  float* __restrict__ out_colours, uint8_t* __restrict__ absorbed) {
     SceneArg S = *kernel_arguments<SceneRec>();   // the first argument, read in place
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long long last = n - 1;
+    const bool live = (long long)blockIdx.x * blockDim.x + threadIdx.x < n;
+    // (lanes past the end ride along on the last hit: the unit vectors are drawn by whole wavefronts)
+    const long long i = live ? (long long)blockIdx.x * blockDim.x + threadIdx.x : last;
     HitRecord h;
     for (int a = 0; a < 3; ++a) { h.p[a] = points[i * 3 + a]; h.n[a] = normals[i * 3 + a]; }
     h.uv[0] = uvs[i * 2]; h.uv[1] = uvs[i * 2 + 1];
@@ -583,9 +636,12 @@ __global__ __launch_bounds__(256) void k_scatter(const SceneRec, int material_in
     h.material = material_index;
     PathKey key;
     key.k0 = k0; key.k1 = k1; key.x = (uint32_t)px[i]; key.y = (uint32_t)py[i]; key.s = (uint32_t)ps[i];
+    const MaterialRec& M = S.materials[material_index];
+    float vx, vy, vz;
+    wave_unit_vectors(key, (uint32_t)bounce, live && draws_unit_vector(M.kind, M.fuzzy), vx, vy, vz);
+    if (!live) return;
     Scattered sc;
-    scatter_one(S, S.materials[material_index], key, (uint32_t)bounce, dirs[i * 3], dirs[i * 3 + 1],
-                dirs[i * 3 + 2], h, sc);
+    scatter_one(S, M, key, (uint32_t)bounce, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], h, vx, vy, vz, sc);
     for (int a = 0; a < 3; ++a) { out_dirs[i * 3 + a] = sc.d[a]; out_colours[i * 3 + a] = sc.col[a]; }
     absorbed[i] = sc.absorbed ? 1 : 0;
 }
@@ -1614,6 +1670,11 @@ static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int
         HIP_TRY(ctx, hipMemsetAsync(next_batch, 0, sizeof(unsigned long long), st));
         A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
         A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
+        if (A.n_batches >= (1ll << 32))
+            return fail(ctx, WRT_E_LIMIT, "wrt_render: more than 2^32 batches of 64 paths in one launch "
+                                          "(width/8 x height/8 x samples): render the samples in several calls");
+        magic_for((uint32_t)ns, A.samples_magic, A.samples_shift);
+        magic_for((uint32_t)A.tiles_x, A.tiles_x_magic, A.tiles_x_shift);
         const bool walks = ctx->hierarchy != 0 && ctx->largest_tree_group >= ctx->hierarchy;
         const int instance = walks ? 1 : ctx->render_instance;
         void (*const kernel)(const RenderLaunch) = render_instance(instance);

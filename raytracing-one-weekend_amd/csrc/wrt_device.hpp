@@ -105,10 +105,18 @@ struct SceneRec {
 typedef const WRT_CONST SceneRec& SceneArg;
 
 // ------------------------------------------------------------------ RNG
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+// Philox-4x32 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) with
+// seven rounds, the fewest that paper's authors found to pass the whole of BigCrush (ten is their
+// default, with a safety margin this renderer's few draws per path do not need): three rounds fewer
+// are 30 % fewer of the generator's instructions, which are about a tenth of a sphere scene's frame.
+#ifndef WRT_PHILOX_ROUNDS
+#define WRT_PHILOX_ROUNDS 7        // (another number is for measurements only: the fixtures and the oracle use seven)
+#endif
+enum { PHILOX_ROUNDS = WRT_PHILOX_ROUNDS };
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < PHILOX_ROUNDS; ++i) {
         // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low one
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -124,7 +132,7 @@ struct PathKey { uint32_t x, y, s, k0, k1; };
 
 __device__ __forceinline__ void keyed_words(const PathKey& k, uint32_t purpose, uint32_t bounce,
                                             uint32_t attempt, uint32_t out[4]) {
-    philox4x32_10(k.x, k.y, k.s, purpose | (bounce << 4) | (attempt << 12), k.k0, k.k1, out);
+    philox4x32(k.x, k.y, k.s, purpose | (bounce << 4) | (attempt << 12), k.k0, k.k1, out);
 }
 
 __device__ __forceinline__ double unit_interval(uint32_t r) { return (double)r * 2.3283064365386963e-10; }
@@ -153,22 +161,73 @@ __device__ __forceinline__ void unit_candidates(const uint32_t w[4], float even[
     }
 }
 
-// numpy_random_unit_vecs (materials.py:401-431) for one path
-__device__ __forceinline__ void keyed_unit_vector(const PathKey& k, uint32_t bounce, float& vx, float& vy, float& vz) {
-    uint32_t r[4];
-    float x, y, z, len2;
-    uint32_t call = 0;
-    while (true) {
-        keyed_words(k, PURPOSE_UNITVEC, bounce, call, r);
-        float even[3], odd[3];
-        unit_candidates(r, even, odd);
-        x = even[0]; y = even[1]; z = even[2];
-        len2 = (x * x + y * y) + z * z;
-        if (!(len2 > 1.0f || len2 < 0.00001f)) break;
-        x = odd[0]; y = odd[1]; z = odd[2];
-        len2 = (x * x + y * y) + z * z;
-        if (!(len2 > 1.0f || len2 < 0.00001f)) break;
-        ++call;
+// The first acceptable of the two candidates of one UNITVEC call (materials.py:417-420: rejected
+// when the squared length is above 1 or below 1e-5); -> accepted
+__device__ __forceinline__ bool accept_unit_candidate(const uint32_t w[4], float& x, float& y, float& z, float& len2) {
+    float even[3], odd[3];
+    unit_candidates(w, even, odd);
+    const float le = (even[0] * even[0] + even[1] * even[1]) + even[2] * even[2];
+    const float lo = (odd[0] * odd[0] + odd[1] * odd[1]) + odd[2] * odd[2];
+    const bool ok_even = !(le > 1.0f || le < 0.00001f), ok_odd = !(lo > 1.0f || lo < 0.00001f);
+    x = ok_even ? even[0] : odd[0]; y = ok_even ? even[1] : odd[1]; z = ok_even ? even[2] : odd[2];
+    len2 = ok_even ? le : lo;
+    return ok_even || ok_odd;
+}
+
+// numpy_random_unit_vecs (materials.py:401-431) for the paths of a wavefront that want a vector.
+// Must be called by the whole wavefront; lanes with `want` false get an unspecified vector.
+//
+// A path takes the first acceptable candidate of its own stream, whichever lane computes it.  Round
+// 0: every lane looks at call 0 of its own path (candidates 0 and 1; about a quarter of the lanes
+// fail both).  After that the lanes still without a vector are few, and a round in which each of them
+// tried one more call alone would cost the whole wavefront a generator call for a handful of lanes.
+// Instead the wavefront's lanes are dealt out among them, `per` lanes (a power of two) to each:
+// helper j of a pending path computes call next + j of THAT path's stream (the path's x, y, sample
+// and bounce come over by ds_bpermute), and the path takes the result of the lowest call that has
+// an acceptable candidate - the same candidate its own loop would have stopped at.  With four
+// helpers a path is still pending after the round once in 350 times.
+__device__ __forceinline__ void wave_unit_vectors(const PathKey& k, uint32_t bounce, bool want, float& vx, float& vy,
+                                                  float& vz) {
+    float x = 0.0f, y = 0.0f, z = 1.0f, len2 = 1.0f;
+    bool pending = false;
+    if (want) {
+        uint32_t w[4];
+        keyed_words(k, PURPOSE_UNITVEC, bounce, 0, w);
+        pending = !accept_unit_candidate(w, x, y, z, len2);
+    }
+    const unsigned lane = threadIdx.x & 63u;
+    uint32_t next_call = 1;                                   // the first call no pending path has looked at
+    for (unsigned long long open = __ballot(pending); open != 0ull; open = __ballot(pending)) {
+        const int n_open = (int)__popcll(open);
+        const int shift = n_open > 32 ? 0 : n_open > 16 ? 1 : n_open > 8 ? 2 : n_open > 4 ? 3 : 4;   // per <= 16
+        const unsigned per_mask = (1u << shift) - 1u;
+        // the pending lane of rank r tells lane r << shift who it is (all others send to lane 63, which is
+        // no rank's first helper unless every lane is pending, and then nobody else sends); that lane's
+        // group reads it from there
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(open >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)open, 0u));
+        const int told = __builtin_amdgcn_ds_permute((pending ? (rank << shift) : 63) * 4, (int)lane);
+        const int owner4 = __builtin_amdgcn_ds_bpermute((int)(lane & ~per_mask) * 4, told) * 4;
+        const bool helping = (int)(lane >> shift) < n_open;
+        PathKey other = k;                                    // (the key words are the same for every path of a launch)
+        other.x = (uint32_t)__builtin_amdgcn_ds_bpermute(owner4, (int)k.x);
+        other.y = (uint32_t)__builtin_amdgcn_ds_bpermute(owner4, (int)k.y);
+        other.s = (uint32_t)__builtin_amdgcn_ds_bpermute(owner4, (int)k.s);
+        const uint32_t other_bounce = (uint32_t)__builtin_amdgcn_ds_bpermute(owner4, (int)bounce);
+        uint32_t w[4];
+        keyed_words(other, PURPOSE_UNITVEC, other_bounce, next_call + (lane & per_mask), w);
+        float hx, hy, hz, hl;
+        const bool found = accept_unit_candidate(w, hx, hy, hz, hl) && helping;
+        // each pending path takes the lowest of its helpers that found one
+        const unsigned long long finds = __ballot(found);
+        const unsigned long long mine = (finds >> (rank << shift)) & ((2ull << per_mask) - 1ull);
+        const bool got = pending && mine != 0ull;
+        const int from4 = (got ? (rank << shift) + (int)__builtin_ctzll(mine) : (int)lane) * 4;
+        const float tx = __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(hx)));
+        const float ty = __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(hy)));
+        const float tz = __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(hz)));
+        const float tl = __int_as_float(__builtin_amdgcn_ds_bpermute(from4, __float_as_int(hl)));
+        if (got) { x = tx; y = ty; z = tz; len2 = tl; pending = false; }
+        next_call += per_mask + 1u;
     }
     const float len = sqrtf(len2);
     vx = x / len; vy = y / len; vz = z / len;
@@ -389,6 +448,9 @@ struct LaneQueue {
     unsigned* share_list;            // the wave's SHARE_ITEMS (owner lane << 24 | triangle) work items
     unsigned long long* share_best;  // the wave's 64 (ordered t << 32 | triangle) minima, one per owner lane
     int noted;                       // primitives in this lane's block entries
+#if defined(WRT_DRAIN_COUNT)
+    long long count_trips, count_items, count_rounds, count_longest;   // measurement builds: the pooled drain's work
+#endif
 };
 enum { SHARE_ITEMS = 384 };
 #ifndef WRT_TIMING
@@ -807,6 +869,9 @@ __device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, 
                 tagged_first = (lane << 24) | (16u * (entry >> 16) + 15u);
             }
             if (__ballot(open != 0u) == 0ull) break;
+#if defined(WRT_DRAIN_COUNT)
+            q.count_trips += 1;
+#endif
             if (open != 0u) {
                 const unsigned bit = 31u - (unsigned)__builtin_clz(open);
                 open &= ~(1u << bit);
@@ -815,6 +880,15 @@ __device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, 
             }
         }
         const int items = total - chunk < SHARE_ITEMS ? total - chunk : SHARE_ITEMS;
+#if defined(WRT_DRAIN_COUNT)
+        q.count_items += items;
+        q.count_rounds += (items + 63) / 64;
+        {
+            int longest = mine;
+            for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(longest, d, 64); longest = o > longest ? o : longest; }
+            if (chunk == 0) q.count_longest += longest;
+        }
+#endif
         for (int base = 0; base < items; base += 64) {
             const bool have = base + (int)lane < items;
             const unsigned item = have ? q.share_list[base + (int)lane] : 0u;
@@ -1411,16 +1485,20 @@ __host__ __device__ __forceinline__ double fifth_power(double x) {
     return h5 + l5;
 }
 
+// does <Material>.scatter draw a random unit vector (numpy_random_unit_vecs, materials.py:62,274)?
+__device__ __forceinline__ bool draws_unit_vector(int kind, int fuzzy) {
+    return (kind >= 1 && kind <= 5) || (kind == 6 && fuzzy != 0);
+}
+
 // <Material>.scatter (materials.py) for one hit, float64 where main.render()'s
-// float64 hit arrays make the reference evaluate in float64.
+// float64 hit arrays make the reference evaluate in float64.  (vx, vy, vz): the path's random unit
+// vector of this bounce (wave_unit_vectors), read only by materials for which draws_unit_vector() holds.
 __device__ __forceinline__ void scatter_one(SceneArg S, const MaterialRec& M, const PathKey& key,
                                             uint32_t bounce, float dx, float dy, float dz,
-                                            const HitRecord& h, Scattered& out) {
+                                            const HitRecord& h, float vx, float vy, float vz, Scattered& out) {
     const double nx = h.n[0], ny = h.n[1], nz = h.n[2];
     out.absorbed = false;
     if (M.kind >= 1 && M.kind <= 5) {
-        float vx, vy, vz;
-        keyed_unit_vector(key, bounce, vx, vy, vz);
         if (dot64(vx, vy, vz, nx, ny, nz) < 0.0) { vx *= -1.0f; vy *= -1.0f; vz *= -1.0f; }
         out.d[0] = vx; out.d[1] = vy; out.d[2] = vz;
         if (M.kind == 1) {
@@ -1461,8 +1539,6 @@ __device__ __forceinline__ void scatter_one(SceneArg S, const MaterialRec& M, co
         double rx = (double)dx - (nx * 2.0) * dn, ry = (double)dy - (ny * 2.0) * dn, rz = (double)dz - (nz * 2.0) * dn;
         out.col[0] = M.colour_a[0]; out.col[1] = M.colour_a[1]; out.col[2] = M.colour_a[2];
         if (M.fuzzy) {
-            float vx, vy, vz;
-            keyed_unit_vector(key, bounce, vx, vy, vz);
             rx += (double)(vx * M.fuzz); ry += (double)(vy * M.fuzz); rz += (double)(vz * M.fuzz);
             const double len = sqrt(dot64(rx, ry, rz, rx, ry, rz));
             rx /= len; ry /= len; rz /= len;

@@ -12,13 +12,17 @@ from tests import helpers
 
 
 def test_philox_known_answers():
-    # Random123 kat_vectors, philox4x32-10
-    def run(c, k):
-        return [int(v) for v in keyed_rng.philox4x32_10(*c, *k)]
-    assert run((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert run((0xffffffff,) * 4, (0xffffffff,) * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert run((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == \
-        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # Random123 kat_vectors: philox4x32 with 10 rounds (the generator's default) and with 7 (the keyed streams')
+    def run(c, k, rounds):
+        return [int(v) for v in keyed_rng.philox4x32(*c, *k, rounds=rounds)]
+    pi = (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)
+    assert run((0, 0, 0, 0), (0, 0), 10) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run((0xffffffff,) * 4, (0xffffffff,) * 2, 10) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run(*pi, 10) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert keyed_rng.ROUNDS == 7
+    assert run((0, 0, 0, 0), (0, 0), 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert run((0xffffffff,) * 4, (0xffffffff,) * 2, 7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert run(*pi, 7) == [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
 
 
 def test_known_answers_from_reference_tests():

@@ -61,6 +61,28 @@ __global__ void k(float* out, long long* cyc, int iters, float seed) {
                 if (MODE == 42) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) : : "vcc");
                 if (MODE == 43) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(m) : "vcc");
                 if (MODE == 44) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(m) : "s20", "s21");
+                if (MODE == 45) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 46) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 47) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 48) asm volatile("v_cmp_gt_i32 vcc, 0, %0" :: "v"(a[i]) : "vcc");
+                if (MODE == 49) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 50) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 51) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 52) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(a[i]));
+                if (MODE == 53) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]));
+                if (MODE == 54) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
+                if (MODE == 55) asm volatile("v_lshrrev_b32 %0, 11, %0" : "+v"(a[i]));
+                if (MODE == 56) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 57) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 58) asm volatile("v_fma_f32 %0, %0, %1, -%2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 59) asm volatile("v_fma_f32 %0, -%0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+                if (MODE == 60) asm volatile("v_mul_f32_e64 %0, -%0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 61) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(p[i]) : "v"(a[i]));
+                if (MODE == 62) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(p[i]));
+                if (MODE == 63) asm volatile("v_rcp_f64 %0, %0" : "+v"(p[i]));
+                if (MODE == 64) asm volatile("v_sqrt_f64 %0, %0" : "+v"(p[i]));
+                if (MODE == 65) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+                if (MODE == 66) asm volatile("v_readlane_b32 s20, %0, 5" :: "v"(a[i]) : "s20");
                 if (MODE == 25) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(p[i]) : "v"(pm));
             }
         }
@@ -102,6 +124,11 @@ int main() {
     run<32>("v_mul_lo_u32"); run<33>("v_mul_hi_u32"); run<34>("v_mad_u64_u32"); run<35>("v_add_f64"); run<36>("v_fma_f64");
     run<37>("v_xor_b32"); run<38>("v_mul_f64"); run<39>("v_alignbit"); run<40>("v_cndmask");
     run<41>("cndmask sgpr"); run<42>("v_addc vcc"); run<43>("cmp+cndmask vcc"); run<44>("cmp+cndmask sgpr");
+    run<45>("v_or3_b32"); run<46>("v_and_or_b32"); run<47>("v_or_b32"); run<48>("v_cmp_gt_i32"); run<49>("v_max3_f32");
+    run<50>("v_add3_u32"); run<51>("v_lshl_add_u32"); run<52>("v_bfe_u32"); run<53>("v_cvt_f32_u32"); run<54>("v_sqrt_f32");
+    run<55>("v_lshrrev_b32"); run<56>("v_add_u32"); run<57>("v_sub_f32 vgpr"); run<58>("v_fma neg c"); run<59>("v_fma neg a");
+    run<60>("v_mul e64 neg"); run<61>("v_cvt_f64_f32"); run<62>("v_cvt_f32_f64"); run<63>("v_rcp_f64"); run<64>("v_sqrt_f64");
+    run<65>("v_min_f32"); run<66>("v_readlane");
     run<0>("v_fma_f32 again");
     return 0;
 }
