@@ -388,20 +388,24 @@ typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
 // wait for every scalar load in flight; nothing may be scheduled across
 #define WRT_SCALAR_LOADS_ARRIVED()                 \
     do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
         __builtin_amdgcn_s_waitcnt(0xc07f);        \
         __builtin_amdgcn_sched_barrier(0);         \
     } while (0)
 #define WRT_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// (volatile: the fetch stays one wide load issued where it is written; otherwise the compiler narrows it
+// to the numbers used, splits it into two or three loads and sinks a piece of it into the step that uses
+// it, where that step then waits for the piece and for the next record's fetch with it)
 __device__ __forceinline__ TriPair fetch_triangle_pair(const WRT_CONST f32x4* p) {
-    const f32x16a lo = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
-    const f32x2a hi = *reinterpret_cast<const WRT_CONST f32x2a*>(p + 4);
+    const f32x16a lo = *reinterpret_cast<const volatile WRT_CONST f32x16a*>(p);
+    const f32x2a hi = *reinterpret_cast<const volatile WRT_CONST f32x2a*>(p + 4);
     return TriPair{{lo[0], lo[1]},   {lo[2], lo[3]},   {lo[4], lo[5]},   {lo[6], lo[7]},  {lo[8], lo[9]},
                    {lo[10], lo[11]}, {lo[12], lo[13]}, {lo[14], lo[15]}, {hi[0], hi[1]}};
 }
 struct SphereQuad { SpherePair a, b; };
 __device__ __forceinline__ SphereQuad fetch_sphere_quad(const WRT_CONST f32x4* p) {
-    const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
+    const f32x16a v = *reinterpret_cast<const volatile WRT_CONST f32x16a*>(p);
     return SphereQuad{SpherePair{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}},
                       SpherePair{{v[8], v[9]}, {v[10], v[11]}, {v[12], v[13]}, {v[14], v[15]}}};
 }
@@ -411,26 +415,45 @@ __device__ __forceinline__ Ray2 both_halves(const Ray& r) {
     return Ray2{{r.ox, r.ox}, {r.oy, r.oy}, {r.oz, r.oz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}};
 }
 
-// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres in 8
+// An upper bound of the reference's discriminant (sphere_group.py:137-190) for two spheres in 7
 // packed instructions.  It only has to be safe, so it is computed in expanded form about a point
 // g of the group (the median sphere centre): with o' = o - g per lane and c' = c - g per sphere,
-//     (d.co)^2 - |co|^2 + r^2  =  (d.o' - d.c')^2 + (2 o'.c' - |o'|^2) - (|c'|^2 - r^2)
-// two fused dot-product chains that start from the per-lane numbers d.o' and -|o'|^2, and one
-// per-sphere number k (the pair records carry c' and k).  Error budget, u = 2^-24,
-// S = |o'| + |c'|:  the reference's float32 value exceeds the exact expression of its rounded co by
-// at most (8.1 |d|^2 + 5) u S^2 + 2u r^2; the rounded co, o' and c' move the exact expression by at
-// most 4u (|d|^2 + 1) S^2; the fused evaluation below is within (13 |d|^2 + 11) u S^2 + 3u r^2 of
-// its own exact value.  With S^2 <= 2 (|o'|^2 + |c'|^2) the three together are below
-// kappa (|o'|^2 + |c'|^2) + 5u r^2, kappa = (52 |d|^2 + 42) u.  The lane shrinks its |o'|^2 by
-// (1 - kappa); the record's k = |c'|^2 (1 - 250u) - r^2 (1 + 2e-6) holds the rest for |d|^2 <= 4
-// (lanes with longer directions look at every sphere).
-struct SphereBoundRay { f32x2 ox2, oy2, oz2, dx, dy, dz, d_o, minus_oo; };   // each number in both halves
+//     (d.co)^2 - |co|^2 + r^2  =  (d.c')^2 - (|c'|^2 - r^2) + w.c' + L,
+//     w = 2 (o' - (d.o') d),   L = (d.o')^2 - |o'|^2,
+// a dot product with d, its square less one per-sphere number k (the pair records carry c' and k),
+// and a fused chain of three with the per-lane vector w.  L is the same for every sphere of the
+// group, so it is not added at all: the lane compares with its own threshold 1e-5 - L instead.
+// Error budget, u = 2^-24, S = |o'| + |c'|:  the reference's float32 value exceeds the exact
+// expression of its rounded co by at most (8.1 |d|^2 + 5) u S^2 + 2u r^2; the rounded co, o' and c'
+// move the exact expression by at most 4u (|d|^2 + 1) S^2; of the evaluation below, d.c' errs by
+// 3u |d||c'|, its square less k by 7u |d|^2 |c'|^2 + u (|c'|^2 + r^2), the three roundings of the
+// chain by 3u ((|d|^2 + 1) S^2 + r^2), the lane's float32 w by (2.5 |d|^2 + 0.5) u S^2 in w.c', and
+// the lane's L with the subtraction from the threshold by (9 |d|^2 + 7) u |o'|^2.  With
+// S^2 <= 2 (|o'|^2 + |c'|^2) the sum is below
+//     (58.2 |d|^2 + 34) u |o'|^2 + (49.2 |d|^2 + 27) u |c'|^2 + 6u r^2.
+// The lane shrinks its |o'|^2 by (1 - kappa), kappa = 3.7e-6 |d|^2 + 2.7e-6 (a margin on the
+// first term); the record's k = |c'|^2 (1 - 250u) - r^2 (1 + 2e-6) holds the other two for
+// |d|^2 <= 4 (lanes with longer directions, or with |o'|^2 beyond 1e30, look at every sphere).
+struct SphereBoundRay { f32x2 wx, wy, wz, dx, dy, dz; };   // each number in both halves
 __device__ __forceinline__ f32x2 sphere_discriminant_bound2(const SphereBoundRay& r, const SpherePair& s) {
-    const f32x2 h = __builtin_elementwise_fma(-r.dz, s.cz, __builtin_elementwise_fma(-r.dy, s.cy,
-                        __builtin_elementwise_fma(-r.dx, s.cx, r.d_o)));
-    const f32x2 m = __builtin_elementwise_fma(r.oz2, s.cz, __builtin_elementwise_fma(r.oy2, s.cy,
-                        __builtin_elementwise_fma(r.ox2, s.cx, r.minus_oo))) - s.r2;   // s.r2 holds k here
-    return __builtin_elementwise_fma(h, h, m);
+    const f32x2 g = __builtin_elementwise_fma(r.dz, s.cz, __builtin_elementwise_fma(r.dy, s.cy, r.dx * s.cx));
+    const f32x2 a = __builtin_elementwise_fma(g, g, -s.r2);                            // s.r2 holds k here
+    return __builtin_elementwise_fma(r.wz, s.cz, __builtin_elementwise_fma(r.wy, s.cy,
+               __builtin_elementwise_fma(r.wx, s.cx, a)));
+}
+// the lane's half of the bound: -> its threshold (the bound of a sphere it has to look at is above it)
+__device__ __forceinline__ float sphere_bound_setup(const Ray& r, bool active, float gx, float gy, float gz,
+                                                    SphereBoundRay& r2) {
+    const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
+    const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+    const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
+    const float keep = 1.0f - (3.7e-6f * dd + 2.7e-6f);          // 1 - kappa, rounded down
+    const float L = d_o * d_o - oo * keep;
+    const float wx = 2.0f * (ox - d_o * r.dx), wy = 2.0f * (oy - d_o * r.dy), wz = 2.0f * (oz - d_o * r.dz);
+    r2 = SphereBoundRay{{wx, wx}, {wy, wy}, {wz, wz}, {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}};
+    // lanes that ride along can never pass; lanes outside the bound's assumptions (written so that a
+    // NaN is outside) pass always; the threshold leaves room for the rounding of its own subtraction
+    return !active ? __builtin_inff() : ((dd <= 4.0f && oo <= 1.0e30f) ? 0.00000999999f - L : -__builtin_inff());
 }
 
 // Candidates of the vote are not evaluated on the spot: a hit is rare for one
@@ -540,7 +563,15 @@ __device__ __forceinline__ void sphere_step(SceneArg S, const SpherePair& s, int
 __device__ __forceinline__ void sphere_step2(SceneArg S, const SpherePair& s, const SpherePair& s2, int index, int count,
                                              float thr, const SphereBoundRay& r2, LaneQueue& q, int g, int first,
                                              const Ray& r, float t_min, float sentinel, Closest& best) {
-    const f32x2 d = sphere_discriminant_bound2(r2, s), e = sphere_discriminant_bound2(r2, s2);
+    // (the two chains written in turn: a packed instruction that reads the result of the one before it
+    // costs a wait state)
+    f32x2 d = r2.dx * s.cx, e = r2.dx * s2.cx;
+    d = __builtin_elementwise_fma(r2.dy, s.cy, d); e = __builtin_elementwise_fma(r2.dy, s2.cy, e);
+    d = __builtin_elementwise_fma(r2.dz, s.cz, d); e = __builtin_elementwise_fma(r2.dz, s2.cz, e);
+    d = __builtin_elementwise_fma(d, d, -s.r2); e = __builtin_elementwise_fma(e, e, -s2.r2);
+    d = __builtin_elementwise_fma(r2.wx, s.cx, d); e = __builtin_elementwise_fma(r2.wx, s2.cx, e);
+    d = __builtin_elementwise_fma(r2.wy, s.cy, d); e = __builtin_elementwise_fma(r2.wy, s2.cy, e);
+    d = __builtin_elementwise_fma(r2.wz, s.cz, d); e = __builtin_elementwise_fma(r2.wz, s2.cz, e);
     if (__ballot(fmaxf(fmaxf(fmaxf(d.x, d.y), e.x), e.y) > thr) != 0ull) {
         push(q, d.x > thr, index);
         push(q, d.y > thr && index + 1 < count, index + 1);
@@ -555,16 +586,8 @@ __device__ __forceinline__ void sphere_step2(SceneArg S, const SpherePair& s, co
 __device__ __forceinline__ void loop_spheres(SceneArg S, const WRT_CONST f32x4* records, int g, int first,
                                              int count, bool active, const Ray& r, float gx, float gy, float gz,
                                              float t_min, float sentinel, LaneQueue& q, Closest& best) {
-    const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
-    const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
-    const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
-    const float keep = 1.0f - (3.11e-6f * dd + 2.65e-6f);          // 1 - kappa, rounded down
-    // lanes that ride along can never pass; lanes outside the bound's assumptions (or with a NaN
-    // somewhere) always do; the threshold leaves room for the rounding of the bound's last operation
-    const float thr = !active ? __builtin_inff() : (dd <= 4.0f ? 0.00000999999f : -__builtin_inff());
-    const float minus_oo = -(oo * keep);
-    const SphereBoundRay r2 = {{2.0f * ox, 2.0f * ox}, {2.0f * oy, 2.0f * oy}, {2.0f * oz, 2.0f * oz},
-                               {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}, {d_o, d_o}, {minus_oo, minus_oo}};
+    SphereBoundRay r2;
+    const float thr = sphere_bound_setup(r, active, gx, gy, gz, r2);
     const int pairs = (count + 1) >> 1;
     SphereQuad A = fetch_sphere_quad(records), B;
     int j = 0;
@@ -603,14 +626,8 @@ __device__ __forceinline__ void loop_spheres_staged(SceneArg S, const f32x4* rec
                                                     float gz, float t_min, float sentinel, LaneQueue& q,
                                                     Closest& best) {
     const unsigned lane = threadIdx.x & 63u;
-    const float ox = r.ox - gx, oy = r.oy - gy, oz = r.oz - gz;
-    const float dd = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
-    const float d_o = (r.dx * ox + r.dy * oy) + r.dz * oz, oo = (ox * ox + oy * oy) + oz * oz;
-    const float keep = 1.0f - (3.11e-6f * dd + 2.65e-6f);
-    const float thr = !active ? __builtin_inff() : (dd <= 4.0f ? 0.00000999999f : -__builtin_inff());
-    const float minus_oo = -(oo * keep);
-    const SphereBoundRay r2 = {{2.0f * ox, 2.0f * ox}, {2.0f * oy, 2.0f * oy}, {2.0f * oz, 2.0f * oz},
-                               {r.dx, r.dx}, {r.dy, r.dy}, {r.dz, r.dz}, {d_o, d_o}, {minus_oo, minus_oo}};
+    SphereBoundRay r2;
+    const float thr = sphere_bound_setup(r, active, gx, gy, gz, r2);
     const int pairs = (count + 1) >> 1;
     for (int base = 0; base < pairs; base += 32) {
         if (2 * base + (int)lane < 2 * pairs) tile[lane] = records[2 * base + (int)lane];
@@ -768,7 +785,7 @@ __device__ __forceinline__ void loop_triangles(SceneArg S, const WRT_CONST f32x4
 // taken 1e-5 too large for them.
 struct BoundPair { f32x2 cx, cy, cz, k, nx, ny, nz; };                // 4 x f32x4 (last two floats unused)
 __device__ __forceinline__ BoundPair fetch_bound_pair(const WRT_CONST f32x4* p) {
-    const f32x16a v = *reinterpret_cast<const WRT_CONST f32x16a*>(p);
+    const f32x16a v = *reinterpret_cast<const volatile WRT_CONST f32x16a*>(p);
     return BoundPair{{v[0], v[1]}, {v[2], v[3]}, {v[4], v[5]}, {v[6], v[7]}, {v[8], v[9]}, {v[10], v[11]}, {v[12], v[13]}};
 }
 
@@ -809,12 +826,16 @@ __device__ __forceinline__ SphereReject sphere_reject_setup(const Ray& r, bool a
 
 // sign bit set in a half of the result: the exact evaluation may report a hit
 __device__ __forceinline__ f32x2 sphere_reject2(const SphereReject& r, const BoundPair& b) {
-    const f32x2 g = __builtin_elementwise_fma(r.dz, b.cz, __builtin_elementwise_fma(r.dy, b.cy, r.dx * b.cx));
-    const f32x2 t = __builtin_elementwise_fma(r.minus_dd, b.k, __builtin_elementwise_fma(r.vz, b.cz,
-                        __builtin_elementwise_fma(r.vy, b.cy, __builtin_elementwise_fma(r.vx, b.cx, r.s0))));
-    const f32x2 Q = __builtin_elementwise_fma(g, g, t);
-    const f32x2 det = __builtin_elementwise_fma(r.dz, b.nz, __builtin_elementwise_fma(r.dy, b.ny, r.dx * b.nx));
+    // (the three chains written in turn: a packed instruction that reads the result of the one before it
+    // costs a wait state)
+    f32x2 g = r.dx * b.cx, det = r.dx * b.nx, t = __builtin_elementwise_fma(r.vx, b.cx, r.s0);
+    g = __builtin_elementwise_fma(r.dy, b.cy, g); det = __builtin_elementwise_fma(r.dy, b.ny, det);
+    t = __builtin_elementwise_fma(r.vy, b.cy, t);
+    g = __builtin_elementwise_fma(r.dz, b.cz, g); det = __builtin_elementwise_fma(r.dz, b.nz, det);
+    t = __builtin_elementwise_fma(r.vz, b.cz, t);
+    t = __builtin_elementwise_fma(r.minus_dd, b.k, t);
     const f32x2 E = det * det;
+    const f32x2 Q = __builtin_elementwise_fma(g, g, t);
     return __builtin_elementwise_fma(-Q, E, -r.W);                        // sign set: the line comes near enough
 }
 
