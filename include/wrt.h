@@ -114,6 +114,8 @@ typedef struct wrt_stats {
     /* wavefronts of the bounce kernel's launches whose lifetime was measured, the count behind
        clock_ticks[0] (a wavefront whose clock reads came out of order is left out of both) */
     uint64_t wavefronts;
+    /* times a path was put on a lane's shelf (see wrt_set_path_shelf); zero for renders without it */
+    uint64_t shelved_paths;
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */
@@ -213,6 +215,17 @@ int wrt_image_bytes(wrt_ctx* ctx, const float* image, int width, int height, uin
    only the survivors get the full evaluation; results are the same bit for bit.
    on = 0: the full evaluation for every pair.  Takes effect with the next render. */
 int wrt_set_triangle_reject(wrt_ctx* ctx, int on);
+
+/* No counterpart in the reference (a scheduling choice of the bounce kernel, main.py:110-212 has
+   no such thing): with the shelf, a lane of wrt_render's bounce kernel keeps a second path in device
+   memory.  A path that waits for a large group's loop while its wavefront has other work goes
+   there and the lane starts a fresh one, so that a loop finds a taker in more lanes when it runs.
+   mode = -1 (default): used for scenes with two or more large triangle groups, where loops compete
+   for a wavefront's lanes (measured +7 % on two meshes of about 6 000 triangles; with one mesh the
+   shelf costs 2 to 3 %); 0: never; 1: for every scene with a triangle group.  A path is the same
+   whichever lane traces it and whenever, so the results are the same bit for bit in every mode.
+   wrt_render_static has no shelf.  Takes effect with the next render. */
+int wrt_set_path_shelf(wrt_ctx* ctx, int mode);
 
 /* No counterpart in the reference either (its README lists a spatial structure as future
    work).  min_primitives = 0 (default): every (ray, primitive) pair of a group is examined (for a

@@ -21,6 +21,7 @@ struct RenderArgs {
     float* paths;                 // [width*height*n_samples][4]
     unsigned long long* stats;    // wrt_stats layout
     unsigned long long* next_batch;   // work counter of this launch, zero at launch
+    unsigned* shelf;                  // [wavefronts of the grid][SHELF_FIELDS][64]: one waiting path per lane (see k_render); null: none
     int tiles_x, tiles_y;
     long long n_batches;          // 8x8-pixel tile x sample batches of 64 paths (below 2^32)
     // division of a batch number by n_samples and of a tile number by tiles_x without a divide (see magic_divide)
@@ -51,6 +52,10 @@ static void magic_for(uint32_t d, uint32_t& magic, uint32_t& shift) {
 #define WRT_RENDER_BLOCK 256
 #endif
 static constexpr int RENDER_BLOCK = WRT_RENDER_BLOCK;
+// -DWRT_SHELF=0: wrt_render runs without the shelf (see k_render), for measurements
+#ifndef WRT_SHELF
+#define WRT_SHELF 1
+#endif
 static constexpr int STAT_PATHS = WRT_MAX_BOUNCES + 2;
 // paths[.].w = segments traced, plus this mark when the path was still alive
 // at the bounce limit (it then also counts as a ray entering bounce max_bounces)
@@ -75,6 +80,13 @@ enum { LANE_DEAD = 0, LANE_ADVANCE = 1, LANE_PARKED = 2 };
 // -DWRT_TIMING=1: every wave tallies where its time goes (wrt_stats.clock_ticks)
 #ifndef WRT_TIMING
 #define WRT_TIMING 0
+#endif
+#if defined(WRT_TRIP_COUNT)
+// measurement build: trips with lanes to shade and how many, runs of the triangle loops and of the sphere loops and
+// their takers (tools/trip_counts.py)
+#define WRT_COUNT(slot, n) (ticks[slot] += (long long)(n))
+#else
+#define WRT_COUNT(slot, n) ((void)0)
 #endif
 #if WRT_TIMING
 #define WRT_CLOCK() ((long long)__builtin_readcyclecounter())
@@ -127,6 +139,28 @@ __device__ __forceinline__ unsigned long long wave_sum_small(bool take, int coun
 
 struct RenderLaunch { SceneRec S; RenderArgs A; };
 
+// The shelf: a second path per lane, kept in memory.  A path that waits for a large group's loop while
+// the wavefront has other work is put there and its lane takes a fresh path, so that when the loop does
+// run, the lane has a taker for it more often (a lane counts as a taker of a loop when either of its
+// two paths waits for it), and the trips through shading in between are made with full wavefronts.
+// `shelf_word` is the lane's summary of its shelf: 0 = empty, else SHELF_OCCUPIED | the slots the path
+// on it waits for (none: it is ready to be shaded).  What a path is does not depend on which lane traces
+// it or when, so the frames are the same bit for bit with and without (scenes with 32 slots do without:
+// the word's top bit is taken).
+enum { SHELF_FIELDS = 16, SHELF_FROM_TAKERS = 48 };
+static constexpr unsigned SHELF_OCCUPIED = 0x80000000u;
+// one number of the lane's path against the same number of the path on its shelf
+template <typename T>
+__device__ __forceinline__ void shelf_exchange(unsigned* at, bool load, bool store, T& value) {
+    static_assert(sizeof(T) == 4, "one dword per field");
+    unsigned mine, theirs;
+    __builtin_memcpy(&mine, &value, 4);
+    theirs = mine;
+    if (load) theirs = *at;
+    if (store) *at = mine;
+    __builtin_memcpy(&value, &theirs, 4);
+}
+
 // A fresh look at a kernel's arguments.  The compiler cannot carry anything read
 // through the returned pointer across this call, so the values are fetched (scalar
 // loads, cached) in the phase that uses them instead of living in registers, or in
@@ -145,7 +179,9 @@ __device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
 // walk's code (compiled into one kernel it costs the sphere loops 2 % through register allocation).
 // TRIANGLES / LARGE_SPHERES: the scene has triangle groups / sphere groups large enough for the
 // wave-uniform loop; an instance without one of them carries none of its code, registers or LDS.
-template <bool WALK, bool TRIANGLES, bool LARGE_SPHERES>
+// SHELF: lanes keep a second path in memory (see the shelf above): the instance for scenes in which several
+// expensive loops compete for a wavefront's lanes.
+template <bool WALK, bool TRIANGLES, bool LARGE_SPHERES, bool SHELF = false>
 __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
@@ -176,6 +212,12 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
     int state = LANE_DEAD;
     int g = 0;                         // next group of the current segment
     unsigned pending = 0u;             // large groups (by slot) the segment still has to go through, in any order
+    unsigned shelf_word = 0u;          // the path on this lane's shelf (see SHELF_OCCUPIED)
+    bool shelving = false;             // this launch has a shelf, and the scene leaves the word's top bit free
+    if (SHELF) {
+        const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
+        shelving = L.A.shelf != nullptr && L.S.n_slots < 32;
+    }
     Closest best = {sentinel, -1, -1};
     PathKey key;
     key.k0 = k0; key.k1 = k1; key.x = key.y = key.s = 0;
@@ -183,6 +225,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
     Ray ray = {0, 0, 0, 0, 0, 1};
     float cr = 1, cg = 1, cb = 1;
     PairCounts pc = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long shelved = 0;    // paths this wavefront has put on the shelf
     // slot of a path in the output, ray-id order r = (x*H + y)*S + s (main.py:102-104)
     auto out_slot = [](const WRT_CONST RenderArgs& A, const PathKey& k) {
         return ((long long)k.x * A.height + k.y) * A.n_samples + ((int)k.s - A.s_begin);
@@ -197,6 +240,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         // ---- (a) segments that have seen every group: shade, scatter or end --
         const bool shading = state == LANE_ADVANCE && g == n_groups && pending == 0u;
         if (__ballot(shading) != 0ull) {
+            WRT_COUNT(3, 1); WRT_COUNT(4, __popcll(__ballot(shading)));
             const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
             SceneArg S = L.S;
             const WRT_CONST RenderArgs& A = L.A;
@@ -255,7 +299,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         // (a fixed share per wave leaves most of the GPU idle while the waves whose
         // share happened to hold more of the expensive tiles finish)
         for (int pass = 0; pass < 2; ++pass) {
-            const unsigned long long dead = __ballot(state == LANE_DEAD);
+            // (a lane whose shelf holds a path that is ready to go on takes that one back instead, in phase d)
+            const bool vacant = state == LANE_DEAD && !(SHELF && shelf_word == SHELF_OCCUPIED);
+            const unsigned long long dead = __ballot(vacant);
             if (dead == 0ull || drained) break;
             const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
             SceneArg S = L.S;
@@ -291,7 +337,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                 }
             }
             const unsigned in_tile = batch_used + (unsigned)__popcll(dead & ((1ull << lane) - 1ull));
-            if (state == LANE_DEAD && in_tile < 64u) {
+            if (vacant && in_tile < 64u) {
                 const int x = batch_x0 + (int)(in_tile & 7u), y = batch_y0 + (int)(in_tile >> 3);
                 if (x < A.width && y < A.height) {
                     key.x = (uint32_t)x; key.y = (uint32_t)y; key.s = (uint32_t)batch_sample;
@@ -373,18 +419,31 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         bool finished = false;
         for (;;) {
             const unsigned long long parked = __ballot(state == LANE_PARKED);
-            const unsigned long long waiting = __ballot(pending != 0u);
+            const bool waits = pending != 0u;                      // (only a lane that advances has anything pending)
+            const unsigned long long waiting = __ballot(waits);
+            // what the shelf could do for this lane when no loop is run now: take the waiting path so that the
+            // lane can start a fresh one, or give back a path that can go on (one that is ready to be shaded in
+            // place of a waiting one; any path to a lane that has none and gets no fresh one)
+            const bool shelf_full = SHELF && shelf_word != 0u;
+            const bool can_shelve = SHELF && shelving && waits && !shelf_full && !drained && state == LANE_ADVANCE;
+            const bool can_resume = SHELF && shelf_full &&
+                                    ((waits && shelf_word == SHELF_OCCUPIED && state == LANE_ADVANCE) || state == LANE_DEAD);
+            const unsigned long long shelf_moves = SHELF ? __ballot(can_shelve || can_resume) : 0ull;
             const bool more_cheap = (__ballot(state == LANE_ADVANCE && pending == 0u) != 0ull) ||
-                                    ((__ballot(state == LANE_DEAD) != 0ull) && !drained);
-            if (parked == 0ull && waiting == 0ull) { finished = !more_cheap; break; }
+                                    ((__ballot(state == LANE_DEAD) != 0ull) && !drained) || shelf_moves != 0ull;
+            if (parked == 0ull && waiting == 0ull && (!SHELF || __ballot(shelf_full) == 0ull)) {
+                finished = !more_cheap;
+                break;
+            }
             // the slot with the most takers among those with enough of them (any number is enough
-            // when nothing else can make progress)
+            // when nothing else can make progress); a lane is a taker with either of its paths
             int run_g = -1, run_n = 0, run_slot = -1;
             const WRT_CONST int* slots = as_uniform(S.slot_group);
             const int n_slots = S.n_slots;
             const int walk_from = S.hierarchy;
+            const unsigned wanted = SHELF ? (pending | (state == LANE_PARKED ? 0u : (shelf_word & ~SHELF_OCCUPIED))) : pending;
             for (int k = 0; k < n_slots; ++k) {
-                const int n = (int)__popcll(__ballot(((pending >> k) & 1u) != 0u));
+                const int n = (int)__popcll(__ballot(((wanted >> k) & 1u) != 0u));
                 const bool walked = WALK && walk_from != 0 && slots[96 + k] >= walk_from;
                 const int need = slots[(walked ? 64 : 32) + k];
                 if (n > run_n && (n >= need || !more_cheap)) { run_n = n; run_slot = k; }
@@ -401,15 +460,48 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                     if (n > run_n) { run_n = n; run_g = cand; }
                     rest &= ~same;
                 }
-                if (run_g < 0) break;                 // only slots without enough takers yet
             }
             const WRT_CONST GroupRec* ugroups = as_uniform(S.groups);
+            // run_g < 0: only slots without enough takers yet
+            const bool go = run_g >= 0 && !(run_slot < 0 && more_cheap && run_n < ugroups[run_g].takers);
+            if (SHELF) {
+                // paths change places with the shelf: for the loop about to run, the shelf's taker in a lane whose
+                // own path is none; when no loop runs, the moves found above
+                bool load = false, store = false;
+                if (go && run_slot >= 0) {
+                    load = ((pending >> run_slot) & 1u) == 0u && ((shelf_word >> run_slot) & 1u) != 0u && state != LANE_PARKED;
+                    store = load && state == LANE_ADVANCE;
+                } else if (!go) {
+                    load = can_resume;
+                    store = can_shelve || (can_resume && state == LANE_ADVANCE);
+                }
+                if (__ballot(load || store) != 0ull) {
+                    shelved += (unsigned)__popcll(__ballot(store));
+                    const WRT_CONST RenderArgs& A = kernel_arguments<RenderLaunch>()->A;
+                    unsigned* at = A.shelf + ((size_t)(blockIdx.x * (RENDER_BLOCK / 64) + (threadIdx.x >> 6)) * SHELF_FIELDS) * 64 + lane;
+                    shelf_exchange(at + 0 * 64, load, store, ray.ox); shelf_exchange(at + 1 * 64, load, store, ray.oy);
+                    shelf_exchange(at + 2 * 64, load, store, ray.oz); shelf_exchange(at + 3 * 64, load, store, ray.dx);
+                    shelf_exchange(at + 4 * 64, load, store, ray.dy); shelf_exchange(at + 5 * 64, load, store, ray.dz);
+                    shelf_exchange(at + 6 * 64, load, store, cr); shelf_exchange(at + 7 * 64, load, store, cg);
+                    shelf_exchange(at + 8 * 64, load, store, cb); shelf_exchange(at + 9 * 64, load, store, key.x);
+                    shelf_exchange(at + 10 * 64, load, store, key.y); shelf_exchange(at + 11 * 64, load, store, key.s);
+                    shelf_exchange(at + 12 * 64, load, store, bounce); shelf_exchange(at + 13 * 64, load, store, best.t);
+                    shelf_exchange(at + 14 * 64, load, store, best.group); shelf_exchange(at + 15 * 64, load, store, best.prim);
+                    // (every path that changes places has been through all its groups: g == n_groups)
+                    const unsigned from_shelf = shelf_word & ~SHELF_OCCUPIED;
+                    if (store) shelf_word = SHELF_OCCUPIED | pending; else if (load) shelf_word = 0u;
+                    if (load) { pending = from_shelf; state = LANE_ADVANCE; g = n_groups; }
+                    else if (store) { pending = 0u; state = LANE_DEAD; }
+                }
+            }
+            if (!go) break;
             const int type = ugroups[run_g].type, first = ugroups[run_g].first, count = ugroups[run_g].count;
             const WRT_CONST f32x4* records = as_uniform(S.pairs) + ugroups[run_g].pair_base;
-            if (run_slot < 0 && more_cheap && run_n < ugroups[run_g].takers) break;
             const bool mine = run_slot >= 0 ? ((pending >> run_slot) & 1u) != 0u
                                             : (state == LANE_PARKED) && (g == run_g);
+            if (SHELF) run_n = (int)__popcll(__ballot(mine));
             since = WRT_CLOCK();
+            if (type == GROUP_TRIANGLES) { WRT_COUNT(5, 1); WRT_COUNT(6, run_n); } else { WRT_COUNT(2, 1); WRT_COUNT(7, run_n); }
             if (TRIANGLES && (!LARGE_SPHERES || type == GROUP_TRIANGLES)) {
                 pc.triangle += (unsigned long long)run_n * (unsigned)count;
                 const SphereReject k = sphere_reject_setup(ray, mine, ugroups[run_g].edge_max, ugroups[run_g].reach,
@@ -471,6 +563,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         if (pc.triangle_slots) atomicAdd(&A.stats[STAT_PATHS + 6], pc.triangle_slots);
         if (pc.triangle_exact) atomicAdd(&A.stats[STAT_PATHS + 15], pc.triangle_exact);
         if (pc.sphere_exact) atomicAdd(&A.stats[STAT_PATHS + 16], pc.sphere_exact);
+        if (SHELF && shelved) atomicAdd(&A.stats[STAT_PATHS + 18], shelved);
         // (the counter is not guaranteed to run on through every change of the chip's power state: a
         // lifetime that comes out negative or absurdly long is left out)
         const long long lived = (long long)__builtin_readcyclecounter() - born;
@@ -485,7 +578,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         ticks[2] = queue.drain_ticks; ticks[3] = queue.count_trips; ticks[4] = queue.count_items;
         ticks[5] = queue.count_rounds; ticks[6] = queue.count_longest;
 #endif
-#if WRT_TIMING || defined(WRT_DRAIN_COUNT)
+#if WRT_TIMING || defined(WRT_DRAIN_COUNT) || defined(WRT_TRIP_COUNT)
         const int tallies = 8;
 #else
         const int tallies = 2;
@@ -663,13 +756,15 @@ static __device__ __align__(256) unsigned char scratch[STATIC_COUNTER_BYTES + ST
 // 3 % slower than instance 0 on a mesh scene (more spills, not fewer), one with the walk and without
 // the triangle code 1 % slower than instance 1 on the 484-sphere scene walked (the walk's own registers
 // bring the spill scratch back): not kept.  Instance 1 runs only when a group of the scene is walked
-// at the current setting of wrt_set_hierarchy.
-static constexpr int RENDER_INSTANCES = 3;
+// at the current setting of wrt_set_hierarchy.  Instance 3 is instance 0 with the shelf (see k_render), for
+// scenes with two or more expensive triangle loops.
+static constexpr int RENDER_INSTANCES = 4;
 typedef void (*RenderKernel)(const RenderLaunch);
 static RenderKernel render_instance(int k) {
     switch (k) {
         case 1: return k_render<true, true, true>;
         case 2: return k_render<false, false, true>;
+        case 3: return k_render<false, true, true, true>;
         default: return k_render<false, true, true>;
     }
 }
@@ -698,6 +793,8 @@ struct wrt_ctx {
     CameraRec h_cam;
     SceneRec scene;
     bool committed = false;
+    int shelf_mode = -1;         // wrt_set_path_shelf: -1 where it pays (shelf_pays), 0 never, 1 in every scene with triangle groups
+    bool shelf_pays = false;
     int render_instance = 0;     // chosen at commit from the kinds of groups the scene has (see render_instance())
     int largest_tree_group = 0;  // primitives of the largest group that has a hierarchy (0: none has)
     // device copies
@@ -705,6 +802,7 @@ struct wrt_ctx {
     size_t blob_bytes = 0;
     unsigned long long* d_stats = nullptr;
     unsigned long long* d_next_batch = nullptr;
+    unsigned* d_shelf = nullptr;     // one waiting path per lane of the bounce kernel's largest grid (see k_render)
     float* d_paths = nullptr;
     size_t paths_bytes = 0;
     // optional timing of the bounce kernel alone (wrt_profile_*)
@@ -716,7 +814,7 @@ struct wrt_ctx {
     hipStream_t last_stream = nullptr;
     bool used = false;
     // resident workgroups per compute unit of k_render<false> / k_render<true> (asked once)
-    int render_blocks_per_cu[RENDER_INSTANCES] = {1, 1, 1};
+    int render_blocks_per_cu[RENDER_INSTANCES] = {1, 1, 1, 1};
     // this device's copy of the static workspace of wrt_render_static
     unsigned char* static_scratch = nullptr;
 };
@@ -858,6 +956,18 @@ int wrt_create(int device, wrt_ctx** out) {
             per_cu = 1;
         ctx->render_blocks_per_cu[k] = per_cu;
     }
+#if WRT_SHELF
+    {
+        int per_cu = 1;
+        for (int k = 0; k < RENDER_INSTANCES; ++k) per_cu = std::max(per_cu, ctx->render_blocks_per_cu[k]);
+        const size_t bytes = (size_t)ctx->cus * per_cu * (RENDER_BLOCK / 64) * SHELF_FIELDS * 64 * sizeof(unsigned);
+        if ((e = hipMalloc((void**)&ctx->d_shelf, bytes)) != hipSuccess) {
+            (void)hipEventDestroy(ctx->last_use); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_next_batch);
+            delete ctx;
+            return fail(nullptr, WRT_E_HIP, std::string("shelf alloc: ") + hipGetErrorString(e));
+        }
+    }
+#endif
     std::memset(ctx->h_textures, 0, sizeof(ctx->h_textures));
     reset_scene(ctx);
     *out = ctx;
@@ -874,6 +984,7 @@ int wrt_destroy(wrt_ctx* ctx) {
     if (ctx->d_blob) (void)hipFree(ctx->d_blob);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_next_batch) (void)hipFree(ctx->d_next_batch);
+    if (ctx->d_shelf) (void)hipFree(ctx->d_shelf);
     if (ctx->d_paths) (void)hipFree(ctx->d_paths);
     for (auto& pr : ctx->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete ctx;
@@ -1616,6 +1727,12 @@ static int lay_out_blob(wrt_ctx* ctx, unsigned char* device_base, unsigned char*
         bool triangles = false;
         for (const GroupRec& g : ctx->h_groups) triangles = triangles || g.type == GROUP_TRIANGLES;
         ctx->render_instance = triangles ? 0 : 2;
+        // the instance with the shelf: two or more triangle loops that each want (nearly) the whole wavefront
+        // (measured: with one such loop the shelf costs 2 to 3 %, with two it gains 7 %)
+        int expensive = 0;
+        for (const GroupRec& g : ctx->h_groups)
+            expensive += g.type == GROUP_TRIANGLES && g.slot >= 0 && g.takers >= SHELF_FROM_TAKERS;
+        ctx->shelf_pays = expensive >= 2;
         ctx->largest_tree_group = 0;
         for (const GroupRec& g : ctx->h_groups)
             if (g.tree_base >= 0 && g.count > ctx->largest_tree_group) ctx->largest_tree_group = g.count;
@@ -1652,7 +1769,7 @@ static int need_scene(wrt_ctx* ctx, const char* who) {
 // time through the bounce kernel into `paths`, then their per-pixel sums into accum.
 static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int n_total, int per_launch,
                            int max_bounces, float t_min, float t_max, uint64_t seed, float* accum, float* paths,
-                           unsigned long long* next_batch, bool timed, hipStream_t st) {
+                           unsigned long long* next_batch, unsigned* shelf, bool timed, hipStream_t st) {
     const long long n_pixels = (long long)width * height;
     bool capturing = false;
     if (int r = stream_is_capturing(ctx, st, capturing)) return r;
@@ -1667,6 +1784,7 @@ static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int
         A.paths = paths;
         A.stats = ctx->d_stats;
         A.next_batch = next_batch;
+        A.shelf = shelf;
         HIP_TRY(ctx, hipMemsetAsync(next_batch, 0, sizeof(unsigned long long), st));
         A.tiles_x = (width + 7) / 8; A.tiles_y = (height + 7) / 8;
         A.n_batches = (long long)A.tiles_x * A.tiles_y * ns;
@@ -1676,7 +1794,9 @@ static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int
         magic_for((uint32_t)ns, A.samples_magic, A.samples_shift);
         magic_for((uint32_t)A.tiles_x, A.tiles_x_magic, A.tiles_x_shift);
         const bool walks = ctx->hierarchy != 0 && ctx->largest_tree_group >= ctx->hierarchy;
-        const int instance = walks ? 1 : ctx->render_instance;
+        int instance = walks ? 1 : ctx->render_instance;
+        if (instance == 0 && shelf && ctx->scene.n_slots < 32 && (ctx->shelf_mode == 1 || (ctx->shelf_mode < 0 && ctx->shelf_pays)))
+            instance = 3;
         void (*const kernel)(const RenderLaunch) = render_instance(instance);
         int blocks = ctx->cus * ctx->render_blocks_per_cu[instance];
         const long long blocks_wanted = (A.n_batches + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);
@@ -1734,7 +1854,7 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
         }
     }
     return render_launches(ctx, width, height, s_begin, n_total, per_launch, max_bounces, t_min, t_max, seed, accum,
-                           path_colours ? path_colours : ctx->d_paths, ctx->d_next_batch, ctx->profiling,
+                           path_colours ? path_colours : ctx->d_paths, ctx->d_next_batch, ctx->d_shelf, ctx->profiling,
                            (hipStream_t)stream);
 }
 
@@ -1755,7 +1875,7 @@ int wrt_render_static(wrt_ctx* ctx, int width, int height, int s_begin, int s_en
     unsigned char* const ws = ctx->static_scratch;              // this device's copy, by address
     return render_launches(ctx, width, height, s_begin, n_total, per_launch, max_bounces, t_min, t_max, seed, accum,
                            reinterpret_cast<float*>(ws + STATIC_COUNTER_BYTES),
-                           reinterpret_cast<unsigned long long*>(ws), false, (hipStream_t)stream);
+                           reinterpret_cast<unsigned long long*>(ws), nullptr, false, (hipStream_t)stream);
 }
 
 int wrt_finalize(wrt_ctx* ctx, const float* accum, int64_t n_values, int spp_total, float* image, void* stream) {
@@ -1810,6 +1930,13 @@ int wrt_set_triangle_reject(wrt_ctx* ctx, int on) {
     return WRT_OK;
 }
 
+int wrt_set_path_shelf(wrt_ctx* ctx, int mode) {
+    WRT_BIND(ctx);
+    if (mode < -1 || mode > 1) return fail(ctx, WRT_E_ARG, "wrt_set_path_shelf: mode must be -1, 0 or 1");
+    ctx->shelf_mode = mode;
+    return WRT_OK;
+}
+
 int wrt_set_hierarchy(wrt_ctx* ctx, int min_triangles) {
     WRT_BIND(ctx);
     if (min_triangles < 0) return fail(ctx, WRT_E_ARG, "wrt_set_hierarchy: negative triangle count");
@@ -1852,6 +1979,7 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     out->triangle_evaluations = raw[STAT_PATHS + 15];
     out->sphere_evaluations = raw[STAT_PATHS + 16];
     out->wavefronts = raw[STAT_PATHS + 17];
+    out->shelved_paths = raw[STAT_PATHS + 18];
     return WRT_OK;
 }
 

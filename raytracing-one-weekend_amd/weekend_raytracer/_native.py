@@ -45,6 +45,7 @@ class WrtStats(ctypes.Structure):
         ("sphere_lane_slots", ctypes.c_uint64), ("triangle_lane_slots", ctypes.c_uint64),
         ("clock_ticks", ctypes.c_uint64 * 8), ("triangle_evaluations", ctypes.c_uint64),
         ("sphere_evaluations", ctypes.c_uint64), ("wavefronts", ctypes.c_uint64),
+        ("shelved_paths", ctypes.c_uint64),
     ]
 
 
@@ -74,6 +75,7 @@ SIGNATURES = {
     "wrt_profile_enable": [_vp, _i],
     "wrt_profile_read": [_vp, ctypes.POINTER(ctypes.c_double), _ip],
     "wrt_set_triangle_reject": [_vp, _i],
+    "wrt_set_path_shelf": [_vp, _i],
     "wrt_set_hierarchy": [_vp, _i],
     "wrt_stats_reset": [_vp, _vp],
     "wrt_stats_read": [_vp, ctypes.POINTER(WrtStats), _vp],
@@ -144,6 +146,9 @@ class Context:
         preset = int(os.environ.get("WRT_HIERARCHY", "0"))     # see main.HIERARCHY
         if preset:
             self.set_hierarchy(preset)
+        # WRT_PATH_SHELF=1 (or 0): see set_path_shelf; the whole GPU test suite must pass with it as it does without
+        if "WRT_PATH_SHELF" in os.environ:
+            self.set_path_shelf(int(os.environ["WRT_PATH_SHELF"]))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -345,6 +350,12 @@ class Context:
         """Bounding-sphere test in front of the triangle evaluation (default on); same results either way."""
         self.check(self.lib.wrt_set_triangle_reject(self.handle, 1 if on else 0), "wrt_set_triangle_reject")
 
+    def set_path_shelf(self, mode):
+        """Second path per lane of the bounce kernel, kept in device memory: -1 where it pays (default: scenes
+        with two or more large triangle groups), 0 never, 1 in every scene with a triangle group; same
+        results in every mode."""
+        self.check(self.lib.wrt_set_path_shelf(self.handle, int(mode)), "wrt_set_path_shelf")
+
     def set_hierarchy(self, on):
         """Walk large triangle groups through a box hierarchy (default off: every pair is examined, as the
         reference does); same closest hits either way, different amount of work.  True: groups of
@@ -364,7 +375,7 @@ class Context:
                     sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots),
                     clock_ticks=np.array(list(s.clock_ticks), dtype=np.uint64).astype(np.int64),
                     triangle_evaluations=int(s.triangle_evaluations), sphere_evaluations=int(s.sphere_evaluations),
-                    wavefronts=int(s.wavefronts))
+                    wavefronts=int(s.wavefronts), shelved_paths=int(s.shelved_paths))
 
 
 _contexts = {}
