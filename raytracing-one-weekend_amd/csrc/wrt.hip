@@ -147,7 +147,12 @@ struct RenderLaunch { SceneRec S; RenderArgs A; };
 // on it waits for (none: it is ready to be shaded).  What a path is does not depend on which lane traces
 // it or when, so the frames are the same bit for bit with and without (scenes with 32 slots do without:
 // the word's top bit is taken).
-enum { SHELF_FIELDS = 16, SHELF_FROM_TAKERS = 48 };
+#ifndef WRT_SHELF_DEPTH
+#define WRT_SHELF_DEPTH 2
+#endif
+// SHELF_DEPTH: places on a lane's shelf (1 or 2); place p of every lane lies p * (wavefronts of the grid) records on
+enum { SHELF_FIELDS = 16, SHELF_FROM_TAKERS = 48, SHELF_DEPTH = WRT_SHELF_DEPTH };
+static_assert(SHELF_DEPTH == 1 || SHELF_DEPTH == 2, "one or two places");
 static constexpr unsigned SHELF_OCCUPIED = 0x80000000u;
 // one number of the lane's path against the same number of the path on its shelf
 template <typename T>
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
     int state = LANE_DEAD;
     int g = 0;                         // next group of the current segment
     unsigned pending = 0u;             // large groups (by slot) the segment still has to go through, in any order
-    unsigned shelf_word = 0u;          // the path on this lane's shelf (see SHELF_OCCUPIED)
+    unsigned shelf_word = 0u, shelf_word2 = 0u;   // the paths on this lane's shelf (see SHELF_OCCUPIED); the second place only with SHELF_DEPTH 2
     bool shelving = false;             // this launch has a shelf, and the scene leaves the word's top bit free
     if (SHELF) {
         const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         // share happened to hold more of the expensive tiles finish)
         for (int pass = 0; pass < 2; ++pass) {
             // (a lane whose shelf holds a path that is ready to go on takes that one back instead, in phase d)
-            const bool vacant = state == LANE_DEAD && !(SHELF && shelf_word == SHELF_OCCUPIED);
+            const bool vacant = state == LANE_DEAD && !(SHELF && (shelf_word == SHELF_OCCUPIED || shelf_word2 == SHELF_OCCUPIED));
             const unsigned long long dead = __ballot(vacant);
             if (dead == 0ull || drained) break;
             const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
@@ -424,14 +429,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
             // what the shelf could do for this lane when no loop is run now: take the waiting path so that the
             // lane can start a fresh one, or give back a path that can go on (one that is ready to be shaded in
             // place of a waiting one; any path to a lane that has none and gets no fresh one)
-            const bool shelf_full = SHELF && shelf_word != 0u;
-            const bool can_shelve = SHELF && shelving && waits && !shelf_full && !drained && state == LANE_ADVANCE;
-            const bool can_resume = SHELF && shelf_full &&
-                                    ((waits && shelf_word == SHELF_OCCUPIED && state == LANE_ADVANCE) || state == LANE_DEAD);
+            const bool shelf_any = SHELF && (shelf_word | shelf_word2) != 0u;
+            const bool shelf_room = SHELF && (shelf_word == 0u || (SHELF_DEPTH == 2 && shelf_word2 == 0u));
+            const bool shelf_ready = SHELF && (shelf_word == SHELF_OCCUPIED || shelf_word2 == SHELF_OCCUPIED);
+            const bool can_shelve = SHELF && shelving && waits && shelf_room && !drained && state == LANE_ADVANCE;
+            const bool can_resume = SHELF && ((waits && shelf_ready && state == LANE_ADVANCE) || (shelf_any && state == LANE_DEAD));
             const unsigned long long shelf_moves = SHELF ? __ballot(can_shelve || can_resume) : 0ull;
             const bool more_cheap = (__ballot(state == LANE_ADVANCE && pending == 0u) != 0ull) ||
                                     ((__ballot(state == LANE_DEAD) != 0ull) && !drained) || shelf_moves != 0ull;
-            if (parked == 0ull && waiting == 0ull && (!SHELF || __ballot(shelf_full) == 0ull)) {
+            if (parked == 0ull && waiting == 0ull && (!SHELF || __ballot(shelf_any) == 0ull)) {
                 finished = !more_cheap;
                 break;
             }
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
             const WRT_CONST int* slots = as_uniform(S.slot_group);
             const int n_slots = S.n_slots;
             const int walk_from = S.hierarchy;
-            const unsigned wanted = SHELF ? (pending | (state == LANE_PARKED ? 0u : (shelf_word & ~SHELF_OCCUPIED))) : pending;
+            const unsigned wanted = SHELF ? (pending | (state == LANE_PARKED ? 0u : ((shelf_word | shelf_word2) & ~SHELF_OCCUPIED))) : pending;
             for (int k = 0; k < n_slots; ++k) {
                 const int n = (int)__popcll(__ballot(((wanted >> k) & 1u) != 0u));
                 const bool walked = WALK && walk_from != 0 && slots[96 + k] >= walk_from;
@@ -468,17 +474,25 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                 // paths change places with the shelf: for the loop about to run, the shelf's taker in a lane whose
                 // own path is none; when no loop runs, the moves found above
                 bool load = false, store = false;
+                bool second = false;                 // the place on the shelf this lane's move is about
                 if (go && run_slot >= 0) {
-                    load = ((pending >> run_slot) & 1u) == 0u && ((shelf_word >> run_slot) & 1u) != 0u && state != LANE_PARKED;
+                    const bool in_first = ((shelf_word >> run_slot) & 1u) != 0u, in_second = ((shelf_word2 >> run_slot) & 1u) != 0u;
+                    load = ((pending >> run_slot) & 1u) == 0u && (in_first || in_second) && state != LANE_PARKED;
                     store = load && state == LANE_ADVANCE;
+                    second = !in_first;
                 } else if (!go) {
                     load = can_resume;
                     store = can_shelve || (can_resume && state == LANE_ADVANCE);
+                    // a path that is ready before one that waits; an empty place for a path that comes without one going
+                    second = load ? (shelf_word2 == SHELF_OCCUPIED || shelf_word == 0u) && !(shelf_word == SHELF_OCCUPIED)
+                                  : shelf_word != 0u;
                 }
                 if (__ballot(load || store) != 0ull) {
                     shelved += (unsigned)__popcll(__ballot(store));
                     const WRT_CONST RenderArgs& A = kernel_arguments<RenderLaunch>()->A;
-                    unsigned* at = A.shelf + ((size_t)(blockIdx.x * (RENDER_BLOCK / 64) + (threadIdx.x >> 6)) * SHELF_FIELDS) * 64 + lane;
+                    const size_t wavefront = (size_t)(blockIdx.x * (RENDER_BLOCK / 64) + (threadIdx.x >> 6)) +
+                                             (SHELF_DEPTH == 2 && second ? (size_t)gridDim.x * (RENDER_BLOCK / 64) : 0);
+                    unsigned* at = A.shelf + (wavefront * SHELF_FIELDS) * 64 + lane;
                     shelf_exchange(at + 0 * 64, load, store, ray.ox); shelf_exchange(at + 1 * 64, load, store, ray.oy);
                     shelf_exchange(at + 2 * 64, load, store, ray.oz); shelf_exchange(at + 3 * 64, load, store, ray.dx);
                     shelf_exchange(at + 4 * 64, load, store, ray.dy); shelf_exchange(at + 5 * 64, load, store, ray.dz);
@@ -488,9 +502,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                     shelf_exchange(at + 12 * 64, load, store, bounce); shelf_exchange(at + 13 * 64, load, store, best.t);
                     shelf_exchange(at + 14 * 64, load, store, best.group); shelf_exchange(at + 15 * 64, load, store, best.prim);
                     // (every path that changes places has been through all its groups: g == n_groups)
-                    const unsigned from_shelf = shelf_word & ~SHELF_OCCUPIED;
-                    if (store) shelf_word = SHELF_OCCUPIED | pending; else if (load) shelf_word = 0u;
-                    if (load) { pending = from_shelf; state = LANE_ADVANCE; g = n_groups; }
+                    const unsigned word = second ? shelf_word2 : shelf_word;
+                    const unsigned now = store ? (SHELF_OCCUPIED | pending) : (load ? 0u : word);
+                    if (second) shelf_word2 = now; else shelf_word = now;
+                    if (load) { pending = word & ~SHELF_OCCUPIED; state = LANE_ADVANCE; g = n_groups; }
                     else if (store) { pending = 0u; state = LANE_DEAD; }
                 }
             }
@@ -956,18 +971,6 @@ int wrt_create(int device, wrt_ctx** out) {
             per_cu = 1;
         ctx->render_blocks_per_cu[k] = per_cu;
     }
-#if WRT_SHELF
-    {
-        int per_cu = 1;
-        for (int k = 0; k < RENDER_INSTANCES; ++k) per_cu = std::max(per_cu, ctx->render_blocks_per_cu[k]);
-        const size_t bytes = (size_t)ctx->cus * per_cu * (RENDER_BLOCK / 64) * SHELF_FIELDS * 64 * sizeof(unsigned);
-        if ((e = hipMalloc((void**)&ctx->d_shelf, bytes)) != hipSuccess) {
-            (void)hipEventDestroy(ctx->last_use); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_next_batch);
-            delete ctx;
-            return fail(nullptr, WRT_E_HIP, std::string("shelf alloc: ") + hipGetErrorString(e));
-        }
-    }
-#endif
     std::memset(ctx->h_textures, 0, sizeof(ctx->h_textures));
     reset_scene(ctx);
     *out = ctx;
@@ -1853,6 +1856,15 @@ int wrt_render(wrt_ctx* ctx, int width, int height, int s_begin, int s_end, int 
             ctx->paths_bytes = need;
         }
     }
+#if WRT_SHELF
+    // the shelf of the bounce kernel's largest grid, allocated with the first render that uses it
+    if (!ctx->d_shelf && ctx->render_instance == 0 && (ctx->shelf_mode == 1 || (ctx->shelf_mode < 0 && ctx->shelf_pays))) {
+        int per_cu = 1;
+        for (int k = 0; k < RENDER_INSTANCES; ++k) per_cu = std::max(per_cu, ctx->render_blocks_per_cu[k]);
+        const size_t bytes = (size_t)ctx->cus * per_cu * (RENDER_BLOCK / 64) * SHELF_FIELDS * 64 * sizeof(unsigned) * SHELF_DEPTH;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shelf, bytes));
+    }
+#endif
     return render_launches(ctx, width, height, s_begin, n_total, per_launch, max_bounces, t_min, t_max, seed, accum,
                            path_colours ? path_colours : ctx->d_paths, ctx->d_next_batch, ctx->d_shelf, ctx->profiling,
                            (hipStream_t)stream);

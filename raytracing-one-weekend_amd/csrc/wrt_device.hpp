@@ -558,20 +558,26 @@ __device__ __forceinline__ void sphere_step(SceneArg S, const SpherePair& s, int
     }
 }
 
-// two steps with one vote: four spheres, one v_max3_f32, one v_max_f32 and one compare (a vote that
-// comes out true is rare enough for the four notes it then costs not to matter)
-__device__ __forceinline__ void sphere_step2(SceneArg S, const SpherePair& s, const SpherePair& s2, int index, int count,
-                                             float thr, const SphereBoundRay& r2, LaneQueue& q, int g, int first,
-                                             const Ray& r, float t_min, float sentinel, Closest& best) {
-    // (the two chains written in turn: a packed instruction that reads the result of the one before it
-    // costs a wait state)
-    f32x2 d = r2.dx * s.cx, e = r2.dx * s2.cx;
+// the bounds of four spheres (the two chains written in turn: a packed instruction that reads the result of the
+// one before it costs a wait state)
+__device__ __forceinline__ void sphere_bounds4(const SphereBoundRay& r2, const SpherePair& s, const SpherePair& s2,
+                                               f32x2& d, f32x2& e) {
+    d = r2.dx * s.cx; e = r2.dx * s2.cx;
     d = __builtin_elementwise_fma(r2.dy, s.cy, d); e = __builtin_elementwise_fma(r2.dy, s2.cy, e);
     d = __builtin_elementwise_fma(r2.dz, s.cz, d); e = __builtin_elementwise_fma(r2.dz, s2.cz, e);
     d = __builtin_elementwise_fma(d, d, -s.r2); e = __builtin_elementwise_fma(e, e, -s2.r2);
     d = __builtin_elementwise_fma(r2.wx, s.cx, d); e = __builtin_elementwise_fma(r2.wx, s2.cx, e);
     d = __builtin_elementwise_fma(r2.wy, s.cy, d); e = __builtin_elementwise_fma(r2.wy, s2.cy, e);
     d = __builtin_elementwise_fma(r2.wz, s.cz, d); e = __builtin_elementwise_fma(r2.wz, s2.cz, e);
+}
+
+// two steps with one vote: four spheres, one v_max3_f32, one v_max_f32 and one compare (a vote that
+// comes out true is rare enough for the four notes it then costs not to matter)
+__device__ __forceinline__ void sphere_step2(SceneArg S, const SpherePair& s, const SpherePair& s2, int index, int count,
+                                             float thr, const SphereBoundRay& r2, LaneQueue& q, int g, int first,
+                                             const Ray& r, float t_min, float sentinel, Closest& best) {
+    f32x2 d, e;
+    sphere_bounds4(r2, s, s2, d, e);
     if (__ballot(fmaxf(fmaxf(fmaxf(d.x, d.y), e.x), e.y) > thr) != 0ull) {
         push(q, d.x > thr, index);
         push(q, d.y > thr && index + 1 < count, index + 1);
