@@ -154,8 +154,17 @@ def side_measurement(name, seed, device, steps=3, reject=True, with_cpu=True, hi
            "roofline_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
            "executed_frac": round(executed / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4),
            "triangle_pairs_fully_evaluated": round(stats["triangle_evaluations"] / max(1, stats["triangle_pairs"]), 5)
-           if reject or hierarchy else 1.0}
+           if reject or hierarchy else 1.0,
+           # lanes that took part in the large groups' loops / lanes those loops ran with
+           "lane_efficiency": {"triangle_loops": round(stats["triangle_pairs"] / stats["triangle_lane_slots"], 4)
+                               if stats["triangle_lane_slots"] else None,
+                               "sphere_loops": round(stats["sphere_pairs"] / stats["sphere_lane_slots"], 4)
+                               if stats["sphere_lane_slots"] else None},
+           # the bounce kernel's instance with a second and third path per lane in device memory (chosen by the
+           # library for scenes with two or more large triangle groups; same results): paths put there per frame
+           "path_shelf": {"used": stats["shelved_paths"] > 0, "shelved_paths_per_frame": stats["shelved_paths"] // steps}}
     if hierarchy:
+        out["lane_efficiency"] = None          # walked groups spend no lane slots in loops: no such figure
         out["roofline_frac"] = None            # not the reference's work: no brute-force roofline figure
         out["speedup_note"] = "box hierarchy: same closest hits bit for bit, fewer pairs examined than the reference does"
     if with_cpu:

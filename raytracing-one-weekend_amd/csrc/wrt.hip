@@ -1798,8 +1798,13 @@ static int render_launches(wrt_ctx* ctx, int width, int height, int s_begin, int
         magic_for((uint32_t)A.tiles_x, A.tiles_x_magic, A.tiles_x_shift);
         const bool walks = ctx->hierarchy != 0 && ctx->largest_tree_group >= ctx->hierarchy;
         int instance = walks ? 1 : ctx->render_instance;
+#if !WRT_TIMING
+        // (not in a -DWRT_TIMING=1 build: with the phase tallies compiled in, the instance with the shelf ends in a memory
+        // fault on a scene with two meshes and a sphere field, on which the same source without the tallies passes every
+        // test and the soaks; the cause has not been found, so phase times are taken without the shelf)
         if (instance == 0 && shelf && ctx->scene.n_slots < 32 && (ctx->shelf_mode == 1 || (ctx->shelf_mode < 0 && ctx->shelf_pays)))
             instance = 3;
+#endif
         void (*const kernel)(const RenderLaunch) = render_instance(instance);
         int blocks = ctx->cus * ctx->render_blocks_per_cu[instance];
         const long long blocks_wanted = (A.n_batches + (RENDER_BLOCK / 64) - 1) / (RENDER_BLOCK / 64);

@@ -44,6 +44,10 @@ def scene_objects(name, aspect):
     ("cow_teapot_field_scene", (160, 90, 2, 6)),                      # two meshes and a sphere field
     ("cow_teapot_field_scene", (333, 187, 1, 10)),
     ("numpy_bunnies_scene", (160, 90, 3, 10)),                        # four meshes
+    # frames of several paths per lane of the resident grid: every wavefront refills many times
+    ("cow_teapot_field_scene", (960, 540, 4, 10)),
+    ("numpy_bunnies_scene", (1280, 720, 3, 10)),
+    ("cloth_bunny_scene", (1001, 563, 5, 10)),
 ])
 def test_shelf_changes_nothing(name, size):
     w, h, s, b = size
