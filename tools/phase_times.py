@@ -57,8 +57,9 @@ def run(name):
               f"{st['triangle_evaluations'] / max(1, st['cull_tests']):.2f} per (ray, group)")
     # (walked groups spend no lane slots in loops: with WRT_HIERARCHY set the figures cover the remaining loops' slots only)
     if not int(os.environ.get("WRT_HIERARCHY", "0")):
-        print(f"  lane efficiency tri {st['triangle_pairs'] / max(1, st['triangle_lane_slots']):.3f} "
-              f"sph {st['sphere_pairs'] / max(1, st['sphere_lane_slots']):.3f}")
+        tri = f"{st['triangle_pairs'] / st['triangle_lane_slots']:.3f}" if st['triangle_lane_slots'] else "-"
+        sph = f"{st['sphere_pairs'] / st['sphere_lane_slots']:.3f}" if st['sphere_lane_slots'] else "-"
+        print(f"  lane efficiency of the large groups' loops: triangles {tri}, spheres {sph}")
     ctx.close()
 
 
