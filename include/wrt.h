@@ -116,6 +116,10 @@ typedef struct wrt_stats {
     uint64_t wavefronts;
     /* times a path was put on a lane's shelf (see wrt_set_path_shelf); zero for renders without it */
     uint64_t shelved_paths;
+    /* paths the bounce kernel ended because their state named a primitive, pixel or sample that does not exist
+       (the kernel checks before it follows a hit into the scene's arrays or writes a path's record): always
+       zero unless something has damaged a path; a render with a non-zero count is not to be trusted */
+    uint64_t damaged_paths;
 } wrt_stats;
 
 /* ---- context ---------------------------------------------------------- */

@@ -249,7 +249,19 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
             const WRT_CONST RenderLaunch& L = *kernel_arguments<RenderLaunch>();
             SceneArg S = L.S;
             const WRT_CONST RenderArgs& A = L.A;
-            const bool hit = shading && best.t < t_max;
+            bool hit = shading && best.t < t_max;
+            // A hit is one the loops found, so it names a primitive of the scene.  A path whose hit does not has been
+            // damaged on its way (nothing in this kernel is known to do that): it is ended here and counted
+            // (wrt_stats.damaged_paths), not followed into memory that is not the scene's.
+            bool damaged = false;
+            if (hit) {
+                damaged = (unsigned)best.group >= (unsigned)n_groups;
+                if (!damaged) {
+                    const GroupRec& G = S.groups[best.group];
+                    damaged = (unsigned)(best.prim - G.first) >= (unsigned)G.count;
+                }
+                hit = !damaged;
+            }
             // The random unit vectors of all the wavefront's hits that take one are drawn together, and
             // before the hit records are made: all the draw needs to know is the material's kind, and
             // the fewer numbers are alive across it the better.
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                     cr *= sc.col[0]; cg *= sc.col[1]; cb *= sc.col[2];
                     done = sc.absorbed;
                 }
-            } else if (shading) {
+            } else if (shading && !damaged) {
                 // sky, main.py:206-207
                 const float ts = (ray.dy + 1.0f) * 0.5f;
                 cr *= (1.0f - ts) * S.horizon[0] + ts * S.zenith[0];
@@ -290,9 +302,13 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
                     mark += SURVIVOR_MARK;
                     done = true;
                 }
-                if (done) {
+                // (its record goes where its pixel and sample say: they are looked at like the hit)
+                damaged = damaged || key.x >= (uint32_t)A.width || key.y >= (uint32_t)A.height ||
+                          (uint32_t)((int)key.s - A.s_begin) >= (uint32_t)A.n_samples;
+                if (damaged) atomicAdd(&A.stats[STAT_PATHS + 19], 1ull);          // (never, as far as anyone knows)
+                if (done || damaged) {
                     f32x4 rec = {cr, cg, cb, (float)mark};
-                    reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
+                    if (!damaged) reinterpret_cast<f32x4*>(A.paths)[out_slot(A, key)] = rec;
                     state = LANE_DEAD;
                 } else {
                     g = 0; best.t = sentinel; best.group = -1; best.prim = -1;
@@ -950,7 +966,8 @@ int wrt_create(int device, wrt_ctx** out) {
     ctx->cus = prop.multiProcessorCount;
     if ((e = hipMalloc((void**)&ctx->d_stats, sizeof(wrt_stats))) != hipSuccess ||
         (e = hipMemset(ctx->d_stats, 0, sizeof(wrt_stats))) != hipSuccess ||
-        (e = hipMalloc((void**)&ctx->d_next_batch, 256)) != hipSuccess) {
+        (e = hipMalloc((void**)&ctx->d_next_batch, 256)) != hipSuccess ||
+        (e = hipMemset(ctx->d_next_batch, 0, 256)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, WRT_E_HIP, std::string("stats alloc: ") + hipGetErrorString(e));
     }
@@ -1997,6 +2014,7 @@ int wrt_stats_read(wrt_ctx* ctx, wrt_stats* out, void* stream) {
     out->sphere_evaluations = raw[STAT_PATHS + 16];
     out->wavefronts = raw[STAT_PATHS + 17];
     out->shelved_paths = raw[STAT_PATHS + 18];
+    out->damaged_paths = raw[STAT_PATHS + 19];
     return WRT_OK;
 }
 

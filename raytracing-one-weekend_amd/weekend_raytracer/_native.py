@@ -45,7 +45,7 @@ class WrtStats(ctypes.Structure):
         ("sphere_lane_slots", ctypes.c_uint64), ("triangle_lane_slots", ctypes.c_uint64),
         ("clock_ticks", ctypes.c_uint64 * 8), ("triangle_evaluations", ctypes.c_uint64),
         ("sphere_evaluations", ctypes.c_uint64), ("wavefronts", ctypes.c_uint64),
-        ("shelved_paths", ctypes.c_uint64),
+        ("shelved_paths", ctypes.c_uint64), ("damaged_paths", ctypes.c_uint64),
     ]
 
 
@@ -366,10 +366,15 @@ class Context:
     def stats_reset(self):
         self.check(self.lib.wrt_stats_reset(self.handle, self.stream()), "wrt_stats_reset")
 
-    def stats(self):
+    def stats(self, strict=True):
+        """-> the counters since the last reset.  A render that had to end damaged paths (see wrt_stats.damaged_paths
+        in wrt.h; never known to happen) is not to be trusted: NativeError unless strict is False."""
         s = WrtStats()
         self.check(self.lib.wrt_stats_read(self.handle, ctypes.byref(s), self.stream()), "wrt_stats_read")
-        return dict(rays_per_bounce=np.array(list(s.rays_per_bounce), dtype=np.int64), paths=int(s.paths),
+        if strict and s.damaged_paths:
+            raise NativeError(f"the bounce kernel ended {int(s.damaged_paths)} paths whose state named a primitive, "
+                              "pixel or sample that does not exist: this render is not to be trusted")
+        return dict(damaged_paths=int(s.damaged_paths), rays_per_bounce=np.array(list(s.rays_per_bounce), dtype=np.int64), paths=int(s.paths),
                     sphere_pairs=int(s.sphere_pairs), triangle_pairs=int(s.triangle_pairs),
                     cull_tests=int(s.cull_tests), disk_pairs=int(s.disk_pairs),
                     sphere_lane_slots=int(s.sphere_lane_slots), triangle_lane_slots=int(s.triangle_lane_slots),

@@ -25,9 +25,9 @@ def test_header_symbols_are_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    # wrt_material: 2 int32 + 6 float + 6 double + 2 double; wrt_stats: 64 + 7 + 8 + 4 uint64
+    # wrt_material: 2 int32 + 6 float + 6 double + 2 double; wrt_stats: 64 + 7 + 8 + 5 uint64
     assert ctypes.sizeof(_native.WrtMaterial) == 8 + 24 + 48 + 16
-    assert ctypes.sizeof(_native.WrtStats) == 8 * (64 + 7 + 8 + 4)
+    assert ctypes.sizeof(_native.WrtStats) == 8 * (64 + 7 + 8 + 5)
 
 
 def test_create_fails_loudly_without_gpu():
