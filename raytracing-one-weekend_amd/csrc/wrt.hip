@@ -123,20 +123,6 @@ static constexpr int TREE_VISIT_COST = WRT_TREE_VISIT_COST;   // wave-instructio
 #ifndef WRT_WAVES_PER_SIMD_WALK
 #define WRT_WAVES_PER_SIMD_WALK WRT_WAVES_PER_SIMD
 #endif
-// Sum of `count` over the lanes with `take` set (each evaluated `count` pairs of
-// a small group on its own); must be called by the whole wave; wave-uniform result.
-__device__ __forceinline__ unsigned long long wave_sum_small(bool take, int count) {
-    unsigned long long total = 0;
-    unsigned long long rest = __ballot(take);
-    while (rest != 0ull) {                       // one trip per distinct group size present
-        const int c = __builtin_amdgcn_readlane(count, (int)__builtin_ctzll(rest));
-        const unsigned long long same = __ballot(take && count == c);
-        total += (unsigned long long)__popcll(same) * (unsigned)c;
-        rest &= ~same;
-    }
-    return total;
-}
-
 struct RenderLaunch { SceneRec S; RenderArgs A; };
 
 // The shelf: a second path per lane, kept in memory.  A path that waits for a large group's loop while
@@ -382,52 +368,52 @@ __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_
         }
         WRT_TALLY(5, since); since = WRT_CLOCK();
         // ---- (c) walk the groups a lane can handle on its own ----------------
-        // The loop is wave-uniform (it runs while any lane still advances) so that the
-        // tallies can be kept in scalar registers.
+        // The lanes that advance are nearly always at the same group (a segment starts at group 0 in the trip that
+        // made it; only a lane coming back from a group gone through in scene order is elsewhere), so the walk takes
+        // one group at a time, the one the first advancing lane is at, for all the lanes that are there: the
+        // group's record and the primitives of a small group come through scalar loads, the tallies are scalar
+        // products.  Lanes elsewhere wait their turn.
         SceneArg S = kernel_arguments<RenderLaunch>()->S;
         while (true) {
-            const bool adv = (state == LANE_ADVANCE) && (g < n_groups);
-            if (__ballot(adv) == 0ull) break;
-            int type = -1, first = 0, count = 0;
-            bool small = false;
-            if (adv) {
-                const GroupRec& G = S.groups[g];
-                type = G.type; first = G.first; count = G.count;
-                const int slot = G.slot;
-                if (TRIANGLES && type == GROUP_TRIANGLES) {
-                    if (!cull_pass(ray, G.c[0], G.c[1], G.c[2], G.c[3])) {
-                        ++g; count = 0;                       // culled: next group
-                    } else if (slot >= 0) {
-                        pending |= 1u << slot; ++g; count = 0;
-                    } else if (count > CHEAP_GROUP_MAX) {
-                        state = LANE_PARKED; count = 0;
-                    } else {
-                        small = true;
-                        lane_triangles(S, g, first, count, ray, t_min, t_max, best);
-                        ++g;
-                    }
-                } else if (type == GROUP_SPHERES) {
-                    if (slot >= 0) {
-                        pending |= 1u << slot; ++g; count = 0;
-                    } else if (count > CHEAP_GROUP_MAX) {
-                        state = LANE_PARKED; count = 0;
-                    } else {
-                        small = true;
-                        lane_spheres(S, g, first, count, ray, t_min, sentinel, best);
-                        ++g;
-                    }
+            const unsigned long long advancing = __ballot((state == LANE_ADVANCE) && (g < n_groups));
+            if (advancing == 0ull) break;
+            const int at = __builtin_amdgcn_readlane(g, (int)__builtin_ctzll(advancing));
+            const bool here = (state == LANE_ADVANCE) && g == at;
+            const unsigned n_here = (unsigned)__popcll(__ballot(here));
+            const WRT_CONST GroupRec& G = as_uniform(S.groups)[at];
+            const int type = G.type, first = G.first, count = G.count, slot = G.slot;
+            if (TRIANGLES && type == GROUP_TRIANGLES) {
+                const bool pass = here && cull_pass(ray, G.c[0], G.c[1], G.c[2], G.c[3]);
+                pc.cull += n_here;
+                if (slot >= 0) {
+                    if (pass) pending |= 1u << slot;
+                    if (here) ++g;
+                } else if (count > CHEAP_GROUP_MAX) {
+                    if (pass) state = LANE_PARKED; else if (here) ++g;
                 } else {
-                    float t;
-                    if (disk_hit(ray, G.c, G.n, t_min, t_max, sentinel, t) && t < best.t) {
-                        best.t = t; best.group = g; best.prim = 0;
-                    }
-                    ++g;
+                    pc.triangle += (unsigned long long)__popcll(__ballot(pass)) * (unsigned)count;
+                    if (pass) uniform_triangles(S, at, first, count, ray, t_min, t_max, best);
+                    if (here) ++g;
                 }
+            } else if (type == GROUP_SPHERES) {
+                if (slot >= 0) {
+                    if (here) { pending |= 1u << slot; ++g; }
+                } else if (count > CHEAP_GROUP_MAX) {
+                    if (here) state = LANE_PARKED;
+                } else {
+                    pc.sphere += (unsigned long long)n_here * (unsigned)count;
+                    if (here) { uniform_spheres(S, at, first, count, ray, t_min, sentinel, best); ++g; }
+                }
+            } else {
+                pc.disk += n_here;
+                float c[4], n[4];
+                for (int a = 0; a < 4; ++a) { c[a] = G.c[a]; n[a] = G.n[a]; }
+                float t;
+                if (disk_hit(ray, c, n, t_min, t_max, sentinel, t) && here && t < best.t) {
+                    best.t = t; best.group = at; best.prim = 0;
+                }
+                if (here) ++g;
             }
-            if (TRIANGLES) pc.cull += __popcll(__ballot(type == GROUP_TRIANGLES));
-            pc.disk += __popcll(__ballot(type == GROUP_DISK));
-            if (TRIANGLES) pc.triangle += wave_sum_small(small && type == GROUP_TRIANGLES, count);
-            pc.sphere += wave_sum_small(small && type == GROUP_SPHERES, count);
         }
         WRT_TALLY(6, since);
         // ---- (d) run one large group's loop when it pays ---------------------

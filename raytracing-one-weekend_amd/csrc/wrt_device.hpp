@@ -1364,6 +1364,34 @@ __device__ __forceinline__ void lane_triangles(SceneArg S, int g, int first, int
     }
 }
 
+// The same for the lanes of a wavefront that are at the same small group: `first` and `count` are wave-uniform and the
+// primitives come through scalar loads.
+__device__ __forceinline__ void uniform_spheres(SceneArg S, int g, int first, int count, const Ray& r,
+                                                float t_min, float sentinel, Closest& best) {
+    const WRT_CONST f32x4* sph = as_uniform(S.sph) + first;
+    for (int j = 0; j < count; ++j) {
+        const f32x4 s = sph[j];
+        float h;
+        const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
+        if (disc > 0.00001f) {
+            const float t = sphere_root(h, disc, t_min, sentinel);
+            if (t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
+        }
+    }
+}
+
+__device__ __forceinline__ void uniform_triangles(SceneArg S, int g, int first, int count, const Ray& r,
+                                                  float t_min, float t_max, Closest& best) {
+    const WRT_CONST f32x4* tri = as_uniform(S.tri) + 2 * first;
+    const WRT_CONST float* bz = as_uniform(S.tri_bz) + first;
+    for (int j = 0; j < count; ++j) {
+        const f32x4 a = tri[2 * j], b = tri[2 * j + 1];
+        const TriTerms k = triangle_terms(r, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, bz[j]);
+        float t;
+        if (triangle_exact(k, t_min, t_max, t) && t < best.t) { best.t = t; best.group = g; best.prim = first + j; }
+    }
+}
+
 // One ray per lane against groups [g_begin, g_end), every lane walking the
 // groups together (stage entry point wrt_intersect).  Every lane of the
 // wavefront must call this; `live` masks lanes without a ray.
