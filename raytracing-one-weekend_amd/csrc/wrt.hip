@@ -123,6 +123,13 @@ static constexpr int TREE_VISIT_COST = WRT_TREE_VISIT_COST;   // wave-instructio
 #ifndef WRT_WAVES_PER_SIMD_WALK
 #define WRT_WAVES_PER_SIMD_WALK WRT_WAVES_PER_SIMD
 #endif
+// The instances with the triangle code but without the walk (mesh scenes): 5 (96 VGPRs).  At 6 the general instance
+// spilled 37 VGPRs (104 bytes of scratch per lane, written and read around every loop run: 11.6 GB of HBM traffic per
+// frame of the 644-triangle mesh scene) and the instance with the shelf 71; at 5 neither spills a vector register,
+// and the frames are 0.3 to 1 % faster (4: 4 to 5 % slower).
+#ifndef WRT_WAVES_PER_SIMD_MESH
+#define WRT_WAVES_PER_SIMD_MESH 5
+#endif
 struct RenderLaunch { SceneRec S; RenderArgs A; };
 
 // The shelf: a second path per lane, kept in memory.  A path that waits for a large group's loop while
@@ -173,7 +180,8 @@ __device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
 // SHELF: lanes keep a second path in memory (see the shelf above): the instance for scenes in which several
 // expensive loops compete for a wavefront's lanes.
 template <bool WALK, bool TRIANGLES, bool LARGE_SPHERES, bool SHELF = false>
-__global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : WRT_WAVES_PER_SIMD) void k_render(const RenderLaunch) {
+__global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : (TRIANGLES ? WRT_WAVES_PER_SIMD_MESH : WRT_WAVES_PER_SIMD))
+void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
     __shared__ float batch_rays[RENDER_BLOCK / 64][6][64];
@@ -1317,7 +1325,7 @@ static constexpr int TREE_MIN_TRIANGLES = 16;
 #define WRT_TREE_LEAF 4
 #endif
 static constexpr int TREE_LEAF = WRT_TREE_LEAF;                // triangles per leaf where the height allows it
-static constexpr int TREE_MAX_TRIANGLES = 8 << QUEUE_SLOTS;     // 8 per leaf, height QUEUE_SLOTS
+static constexpr int TREE_MAX_TRIANGLES = 8 << TREE_HEIGHT;     // 8 per leaf, height TREE_HEIGHT
 static constexpr int SPHERE_TREE_OUTLIERS = 4;
 // a tree has fewer than 4 f32x4 of nodes and 3 of leaf records per primitive, and the walk's pool packs a
 // leaf's code (offset * 8 + size - 1) into 26 bits beside the lane of the ray's owner
@@ -1493,12 +1501,12 @@ static void build_sphere_tree(wrt_ctx* ctx, GroupRec& g) {
     }
     if (!usable || (int)t.size() < TREE_MIN_TRIANGLES || !(reach < 1e15)) return;
     const int n = (int)t.size();
-    const int leaf_max = n <= (TREE_LEAF << QUEUE_SLOTS) ? TREE_LEAF : 8;
+    const int leaf_max = n <= (TREE_LEAF << TREE_HEIGHT) ? TREE_LEAF : 8;
     std::vector<TreeNode> nodes;
     TreeBox whole;
     // (a ray from WRT_SAH_DISTANCE times the group's reach away: s of sphere_tree_ray_setup with delta = 0)
     const double far = WRT_SAH_DISTANCE * reach;
-    build_tree_range(t, 0, n, leaf_max, QUEUE_SLOTS, 3.1e-6 * far * far + 9.1e-7 * r_max * r_max, nodes, whole);
+    build_tree_range(t, 0, n, leaf_max, TREE_HEIGHT, 3.1e-6 * far * far + 9.1e-7 * r_max * r_max, nodes, whole);
     g.tree_base = (int)ctx->h_tree.size();
     g.tree_leaf_shift = leaf_max <= 2 ? 1 : leaf_max <= 4 ? 2 : 3;
     g.reach2 = std::nextafter((float)reach, INFINITY);
@@ -1545,12 +1553,12 @@ static void build_trees(wrt_ctx* ctx) {
             finite = finite && std::isfinite(k.kappa);
         }
         if (!finite || !(reach2 < 1e30)) continue;
-        const int leaf_max = g.count <= (TREE_LEAF << QUEUE_SLOTS) ? TREE_LEAF : 8;
+        const int leaf_max = g.count <= (TREE_LEAF << TREE_HEIGHT) ? TREE_LEAF : 8;
         std::vector<TreeNode> nodes;
         TreeBox whole;
         // count >= TREE_MIN_TRIANGLES: the root is a node
         // (a unit-length ray from WRT_SAH_DISTANCE times the group's reach away: s of tree_ray_setup)
-        build_tree_range(t, 0, g.count, leaf_max, QUEUE_SLOTS, WRT_SAH_DISTANCE * reach2, nodes, whole);
+        build_tree_range(t, 0, g.count, leaf_max, TREE_HEIGHT, WRT_SAH_DISTANCE * reach2, nodes, whole);
         g.tree_base = (int)ctx->h_tree.size();
         g.tree_leaf_shift = leaf_max <= 2 ? 1 : leaf_max <= 4 ? 2 : 3;
         g.reach2 = std::nextafter((float)reach2, INFINITY);

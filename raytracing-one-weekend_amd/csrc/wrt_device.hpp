@@ -463,7 +463,12 @@ __device__ __forceinline__ float sphere_bound_setup(const Ray& r, bool active, f
 // in a short queue in LDS, in index order, and the wavefront works the queues
 // off together afterwards, each lane fetching its own primitives: a few
 // trips per group instead of one per candidate.
-enum { QUEUE_SLOTS = 12 };
+#ifndef WRT_QUEUE_SLOTS
+#define WRT_QUEUE_SLOTS 12
+#endif
+// TREE_HEIGHT: what the hierarchy builder keeps its trees within (the walk's stack is a ring in the queue slots)
+enum { QUEUE_SLOTS = WRT_QUEUE_SLOTS, TREE_HEIGHT = 12 };
+static_assert(TREE_HEIGHT <= QUEUE_SLOTS, "the walk's stack lives in the queue slots");
 struct LaneQueue {
     unsigned* slot;     // slot[k * 64]: k-th entry of this lane (a primitive's index inside the group, or a block)
     int n;

@@ -162,7 +162,7 @@ int main() {
             w.visit(0, lo, hi, INFINITY, 0);
             for (int j = 0; j < g.count; ++j)
                 if (w.seen[(size_t)j] != 1) { EXPECT(false, "group of %d: sphere %d is held %d times", g.count, j, w.seen[(size_t)j]); break; }
-            EXPECT(w.deepest <= QUEUE_SLOTS, "group of %d spheres: a walk may need %d stack entries", g.count, w.deepest);
+            EXPECT(w.deepest <= TREE_HEIGHT, "group of %d spheres: a walk may need %d stack entries", g.count, w.deepest);
             std::printf("group of %5d spheres:   %d stack entries at most, %d outside the tree\n", g.count, w.deepest, g.n_outliers);
             continue;
         }
@@ -181,7 +181,7 @@ int main() {
         w.visit(0, lo, hi, INFINITY, 0);
         for (int j = 0; j < g.count; ++j)
             if (w.seen[(size_t)j] != 1) { EXPECT(false, "group of %d: triangle %d is in %d leaves", g.count, j, w.seen[(size_t)j]); break; }
-        EXPECT(w.deepest <= QUEUE_SLOTS, "group of %d: a walk may need %d stack entries", g.count, w.deepest);
+        EXPECT(w.deepest <= TREE_HEIGHT, "group of %d: a walk may need %d stack entries", g.count, w.deepest);
         std::printf("group of %5d triangles: %d stack entries at most\n", g.count, w.deepest);
     }
     std::printf(failures ? "%d FAILURES\n" : "tree check passed\n", failures);
