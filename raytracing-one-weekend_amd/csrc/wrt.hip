@@ -182,13 +182,14 @@ __device__ __forceinline__ const WRT_CONST T* kernel_arguments() {
 template <bool WALK, bool TRIANGLES, bool LARGE_SPHERES, bool SHELF = false>
 __global__ __launch_bounds__(RENDER_BLOCK, WALK ? WRT_WAVES_PER_SIMD_WALK : (TRIANGLES ? WRT_WAVES_PER_SIMD_MESH : WRT_WAVES_PER_SIMD))
 void k_render(const RenderLaunch) {
-    __shared__ unsigned queue_slots[RENDER_BLOCK / 64][QUEUE_SLOTS][64];
+    constexpr int SLOTS = (TRIANGLES && !WALK) ? MESH_QUEUE_SLOTS : QUEUE_SLOTS;
+    __shared__ unsigned queue_slots[RENDER_BLOCK / 64][SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
     __shared__ float batch_rays[RENDER_BLOCK / 64][6][64];
     __shared__ unsigned share_list[TRIANGLES ? RENDER_BLOCK / 64 : 1][TRIANGLES ? SHARE_ITEMS : 1];
     __shared__ unsigned long long share_best[TRIANGLES ? RENDER_BLOCK / 64 : 1][TRIANGLES ? 64 : 1];
     const unsigned lane = threadIdx.x & 63u;
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, 0, share_list[TRIANGLES ? threadIdx.x >> 6 : 0],
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, SLOTS, 0, share_list[TRIANGLES ? threadIdx.x >> 6 : 0],
                        share_best[TRIANGLES ? threadIdx.x >> 6 : 0], 0};
 #if defined(WRT_DRAIN_COUNT)
     queue.count_trips = queue.count_items = queue.count_rounds = queue.count_longest = 0;
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256) void k_intersect(const SceneRec, int group, co
     __shared__ unsigned queue_slots[256 / 64][QUEUE_SLOTS][64];
     __shared__ unsigned share_list[256 / 64][SHARE_ITEMS];
     __shared__ unsigned long long share_best[256 / 64][64];
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0, 0, share_list[threadIdx.x >> 6],
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][threadIdx.x & 63u], 0, QUEUE_SLOTS, 0, share_list[threadIdx.x >> 6],
                        share_best[threadIdx.x >> 6], 0};
     closest_hit(S, g0, g1, live, ray, t_min, t_max, queue, best, pc);
     if (!live) return;

@@ -467,11 +467,18 @@ __device__ __forceinline__ float sphere_bound_setup(const Ray& r, bool active, f
 #define WRT_QUEUE_SLOTS 12
 #endif
 // TREE_HEIGHT: what the hierarchy builder keeps its trees within (the walk's stack is a ring in the queue slots)
-enum { QUEUE_SLOTS = WRT_QUEUE_SLOTS, TREE_HEIGHT = 12 };
+// MESH_QUEUE_SLOTS: the slots of the kernel instances that run the triangle loops without the walk (sixteen measure
+// 0.6 % faster there than twelve: fewer, larger drains; the instance with the walk would lose a wavefront per SIMD to them)
+#ifndef WRT_MESH_QUEUE_SLOTS
+#define WRT_MESH_QUEUE_SLOTS 16
+#endif
+enum { QUEUE_SLOTS = WRT_QUEUE_SLOTS, TREE_HEIGHT = 12, MESH_QUEUE_SLOTS = WRT_MESH_QUEUE_SLOTS };
 static_assert(TREE_HEIGHT <= QUEUE_SLOTS, "the walk's stack lives in the queue slots");
+static_assert(MESH_QUEUE_SLOTS >= QUEUE_SLOTS && MESH_QUEUE_SLOTS <= 28, "the pooled drain's entry masks are 32 bits");
 struct LaneQueue {
     unsigned* slot;     // slot[k * 64]: k-th entry of this lane (a primitive's index inside the group, or a block)
     int n;
+    int room;           // entries a lane can hold (QUEUE_SLOTS or MESH_QUEUE_SLOTS: what the kernel laid out)
     long long drain_ticks;   // builds with WRT_TIMING: time spent working queues off
     unsigned* share_list;            // the wave's SHARE_ITEMS (owner lane << 24 | triangle) work items
     unsigned long long* share_best;  // the wave's 64 (ordered t << 32 | triangle) minima, one per owner lane
@@ -480,7 +487,10 @@ struct LaneQueue {
     long long count_trips, count_items, count_rounds, count_longest;   // measurement builds: the pooled drain's work
 #endif
 };
-enum { SHARE_ITEMS = 384 };
+#ifndef WRT_SHARE_ITEMS
+#define WRT_SHARE_ITEMS 384
+#endif
+enum { SHARE_ITEMS = WRT_SHARE_ITEMS };
 #ifndef WRT_TIMING
 #define WRT_TIMING 0
 #endif
@@ -499,7 +509,7 @@ __device__ __forceinline__ void push(LaneQueue& q, bool take, int index) {
 }
 // true when some lane's queue cannot take `entries` more: time to work the queues off
 __device__ __forceinline__ bool short_of_room(const LaneQueue& q, int entries) {
-    return __ballot(q.n > QUEUE_SLOTS - entries) != 0ull;
+    return __ballot(q.n > q.room - entries) != 0ull;
 }
 
 // Block entries: the triangle reject loop looks at 16 triangles between two visits to the queue.
@@ -516,20 +526,7 @@ __device__ __forceinline__ void note_block(LaneQueue& q, int block, unsigned mas
     q.n += (mask != 0u) ? 1 : 0;
     q.noted += __popc(mask);
 }
-__device__ __forceinline__ bool queue_full(const LaneQueue& q) { return __ballot(q.n >= QUEUE_SLOTS) != 0ull; }
-// the lane's next primitive in index order, -1 when its entries are used up
-__device__ __forceinline__ int next_in_blocks(const LaneQueue& q, int& k, unsigned& open, int& block_first) {
-    if (open == 0u && k < q.n) {
-        const unsigned entry = q.slot[k * 64];
-        ++k;
-        open = entry & 0xffffu;
-        block_first = 16 * (int)(entry >> 16);
-    }
-    if (open == 0u) return -1;
-    const int bit = 31 - (int)__builtin_clz(open);
-    open &= ~(1u << bit);
-    return block_first + 15 - bit;
-}
+__device__ __forceinline__ bool queue_full(const LaneQueue& q) { return __ballot(q.n >= q.room) != 0ull; }
 
 // sphere_group.py:190-213 for the queued spheres of each lane
 __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
@@ -546,6 +543,7 @@ __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, i
         }
     }
     q.n = 0;
+    q.noted = 0;
     WRT_DRAIN_END(q);
 }
 
@@ -861,69 +859,87 @@ __device__ __forceinline__ float from_ordered_bits(unsigned o) {
 }
 
 // The lanes' lists differ a lot in length (a ray skimming the mesh passes through dozens of
-// bounding spheres, most pass through a few), so the wave pools them: every lane writes its
-// triangles into one list, the lanes then take 64 items at a time, each borrowing the owner's
+// bounding spheres, most pass through a few), so the wave pools them: the lanes write the
+// triangles of all entries into one list, then take 64 items at a time, each borrowing the owner's
 // ray (ds_bpermute), evaluating the pair exactly as above and lowering the owner's entry of
 // `share_best` with one 64-bit minimum: smaller t wins, equal t goes to the smaller index
 // (numpy.argmin, triangle_group.py:399), and an entry starts at (best.t, 0) so that an equal
 // t of this group never replaces a hit of an earlier group or drain (strict <, main.py:144).
-__device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
-                                                      const TriangleWalk& w, Closest& best,
+// The minimum does not depend on the order of the items, so the list is written in whatever order
+// is quickest: one triangle per lane and trip, and the entries dealt out so that no lane has a long
+// list to itself: entry k of lane c is expanded by lane (c - 16 (k & 3)) mod 64, which spreads the
+// twelve entries of a skimming ray over four lanes (trips per drain: the longest share instead of
+// the longest list).  A trip's items go to consecutive places (v_mbcnt of the ballot), and when
+// fewer than 64 places are left the list's whole rounds of 64 are worked off, the rest moves to its
+// front and the trips go on where they stopped.
+__device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, int g, int first, int count,
+                                                      const Ray& r, const TriangleWalk& w, Closest& best,
                                                       unsigned long long& evaluated) {
+    static_assert(SHARE_ITEMS >= 128, "room for a trip's 64 items");
     WRT_DRAIN_BEGIN(q);
     const unsigned lane = threadIdx.x & 63u;
-    // where this lane's triangles go in the pooled numbering
-    const int mine = q.noted;
-    int upto = mine;
+    int total = q.noted;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int below = __shfl_up(upto, d, 64);
-        if ((int)lane >= d) upto += below;
-    }
-    const int before = upto - mine;
-    const int total = __builtin_amdgcn_readlane(upto, 63);
-    evaluated += (unsigned)total;
+    for (int d = 1; d < 64; d <<= 1) total += __shfl_xor(total, d, 64);
+    total = __builtin_amdgcn_readfirstlane(total);
     // equal t: an earlier group's hit stays (index field 0 cannot be undercut), a later group's goes
     const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32) |
                                      (best.group > g ? 0xffffffffull : 0ull);
     q.share_best[lane] = start;
-    for (int chunk = 0; chunk < total; chunk += SHARE_ITEMS) {
-        // owners write their items of this chunk, one a trip, each lane going through its own
-        // entries at its own pace (a stored entry has a bit set)
-        int number = before - chunk;
-        int k = 0;
-        unsigned open = 0u, tagged_first = 0u;
-        for (;;) {
-            if (open == 0u && k < q.n) {
-                const unsigned entry = q.slot[k * 64];
-                ++k;
+    // the entries this lane expands: rows j, j + 4, j + 8 of the lane 16 j places on, as far as that lane has entries
+    unsigned todo = 0x11111111u & ((1u << q.n) - 1u);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const int there = __builtin_amdgcn_ds_bpermute((int)((lane + 16u * (unsigned)j) & 63u) * 4, q.n);
+        todo |= (0x11111111u << j) & ((1u << there) - 1u);
+    }
+#if defined(WRT_DRAIN_COUNT)
+    {
+        int longest = q.n;
+        for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(longest, d, 64); longest = o > longest ? o : longest; }
+        q.count_longest += longest;
+    }
+#endif
+    const unsigned* const row0 = q.slot - lane;        // the wave's entries: row0[k * 64 + c] is entry k of lane c
+    unsigned open = 0u, tagged_first = 0u;
+    int listed = 0;
+    for (int done = 0; done < total;) {
+        bool exhausted = false;
+        while (listed <= SHARE_ITEMS - 64) {
+            if (open == 0u && todo != 0u) {
+                const unsigned k = (unsigned)__builtin_ctz(todo);
+                todo &= todo - 1u;
+                const unsigned c = (lane + 16u * (k & 3u)) & 63u;
+                const unsigned entry = row0[k * 64u + c];
                 open = entry & 0xffffu;
-                tagged_first = (lane << 24) | (16u * (entry >> 16) + 15u);
+                tagged_first = (c << 24) | (16u * (entry >> 16) + 15u);
             }
-            if (__ballot(open != 0u) == 0ull) break;
+            const unsigned long long writers = __ballot(open != 0u);
+            if (writers == 0ull) { exhausted = true; break; }
 #if defined(WRT_DRAIN_COUNT)
             q.count_trips += 1;
 #endif
             if (open != 0u) {
                 const unsigned bit = 31u - (unsigned)__builtin_clz(open);
                 open &= ~(1u << bit);
-                if ((unsigned)number < (unsigned)SHARE_ITEMS) q.share_list[number] = tagged_first - bit;
-                ++number;
+                const unsigned at = __builtin_amdgcn_mbcnt_hi((unsigned)(writers >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)writers, (unsigned)listed));
+                q.share_list[at] = tagged_first - bit;
             }
+            listed += __popcll(writers);
         }
-        const int items = total - chunk < SHARE_ITEMS ? total - chunk : SHARE_ITEMS;
+        // whole rounds of 64 while more is to come (the rest moves to the front of the list), everything at the end
+        const int items = exhausted ? listed : listed & ~63;
+        evaluated += (unsigned)items;
+        done = exhausted ? total : done + items;
 #if defined(WRT_DRAIN_COUNT)
         q.count_items += items;
         q.count_rounds += (items + 63) / 64;
-        {
-            int longest = mine;
-            for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(longest, d, 64); longest = o > longest ? o : longest; }
-            if (chunk == 0) q.count_longest += longest;
-        }
 #endif
         for (int base = 0; base < items; base += 64) {
-            const bool have = base + (int)lane < items;
-            const unsigned item = have ? q.share_list[base + (int)lane] : 0u;
+            const unsigned item = base + (int)lane < items ? q.share_list[base + (int)lane] : 0xffffffu;
+            // (an index outside the group - only a damaged list could hold one - is left out, not fetched)
+            const bool have = (item & 0xffffffu) < (unsigned)count;
             const int owner4 = (int)(item >> 24) * 4;
             Ray borrowed;
             borrowed.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
@@ -942,6 +958,11 @@ __device__ __forceinline__ void drain_triangle_blocks(SceneArg S, LaneQueue& q, 
                               ((unsigned long long)ordered_bits(t) << 32) | (unsigned long long)(unsigned)prim);
             }
         }
+        if (items < listed) {
+            const unsigned kept = (int)lane < listed - items ? q.share_list[items + (int)lane] : 0u;
+            q.share_list[lane] = kept;
+        }
+        listed -= items;
     }
     const unsigned long long won = q.share_best[lane];
     if (won != start) {
@@ -978,10 +999,10 @@ __device__ __forceinline__ void loop_triangles_rejecting(SceneArg S, const WRT_C
         const int left = count - 16 * block;
         if (left < 16) mask &= 0xffffu << (16 - left);
         note_block(q, block, k.active ? mask : 0u);         // (a NaN ray's verdicts are arbitrary)
-        if (queue_full(q)) drain_triangle_blocks(S, q, g, first, r, w, best, evaluated);
+        if (queue_full(q)) drain_triangle_blocks(S, q, g, first, count, r, w, best, evaluated);
     }
     WRT_SCALAR_LOADS_ARRIVED();
-    drain_triangle_blocks(S, q, g, first, r, w, best, evaluated);
+    drain_triangle_blocks(S, q, g, first, count, r, w, best, evaluated);
 }
 
 // ---- optional: a group's box hierarchy, walked by the wavefront's lanes together ------
