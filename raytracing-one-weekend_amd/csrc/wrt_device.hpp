@@ -532,6 +532,16 @@ __device__ __forceinline__ bool queue_full(const LaneQueue& q) { return __ballot
 __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
                                               float t_min, float sentinel, Closest& best) {
     WRT_DRAIN_BEGIN(q);
+#if defined(WRT_DRAIN_COUNT)
+    {
+        int longest = q.n, sum = q.n;
+        for (int d = 32; d > 0; d >>= 1) {
+            const int o = __shfl_xor(longest, d, 64); longest = o > longest ? o : longest;
+            sum += __shfl_xor(sum, d, 64);
+        }
+        q.count_trips += longest; q.count_items += sum; q.count_longest += longest; q.count_rounds += (sum + 63) / 64;
+    }
+#endif
     for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
         if (k < q.n) {
             const int prim = first + (int)q.slot[k * 64];
