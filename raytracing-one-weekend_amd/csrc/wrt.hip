@@ -186,11 +186,11 @@ void k_render(const RenderLaunch) {
     __shared__ unsigned queue_slots[RENDER_BLOCK / 64][SLOTS][64];
     // camera rays of the wave's current batch, made by all 64 lanes at once when the batch is taken
     __shared__ float batch_rays[RENDER_BLOCK / 64][6][64];
-    __shared__ unsigned share_list[TRIANGLES ? RENDER_BLOCK / 64 : 1][TRIANGLES ? SHARE_ITEMS : 1];
-    __shared__ unsigned long long share_best[TRIANGLES ? RENDER_BLOCK / 64 : 1][TRIANGLES ? 64 : 1];
+    __shared__ unsigned share_list[RENDER_BLOCK / 64][TRIANGLES ? SHARE_ITEMS : SPHERE_SHARE_ITEMS];
+    __shared__ unsigned long long share_best[RENDER_BLOCK / 64][64];
     const unsigned lane = threadIdx.x & 63u;
-    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, SLOTS, 0, share_list[TRIANGLES ? threadIdx.x >> 6 : 0],
-                       share_best[TRIANGLES ? threadIdx.x >> 6 : 0], 0};
+    LaneQueue queue = {&queue_slots[threadIdx.x >> 6][0][lane], 0, SLOTS, 0, share_list[threadIdx.x >> 6],
+                       share_best[threadIdx.x >> 6], 0};
 #if defined(WRT_DRAIN_COUNT)
     queue.count_trips = queue.count_items = queue.count_rounds = queue.count_longest = 0;
 #endif

@@ -528,7 +528,50 @@ __device__ __forceinline__ void note_block(LaneQueue& q, int block, unsigned mas
 }
 __device__ __forceinline__ bool queue_full(const LaneQueue& q) { return __ballot(q.n >= q.room) != 0ull; }
 
-// sphere_group.py:190-213 for the queued spheres of each lane
+// float -> unsigned with the same order (and back)
+__device__ __forceinline__ unsigned ordered_bits(float t) {
+    const unsigned b = __float_as_uint(t);
+    return b ^ ((b >> 31) != 0u ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned o) {
+    return __uint_as_float(o ^ ((o >> 31) != 0u ? 0x80000000u : 0xffffffffu));
+}
+
+// sphere_group.py:190-213 for the queued spheres of the wavefront's lanes.  The lanes' lists differ in length (five
+// entries in the longest against 1.7 on average in a field of 484 spheres), so the wavefront pools them as it does the
+// triangles' (drain_triangle_blocks below): entry k of every lane that has one goes into a list in LDS, at consecutive
+// places (v_mbcnt of the ballot); whenever the list holds 64 items the lanes take one each, borrow the owner's ray
+// (ds_bpermute), evaluate the pair as the reference does and lower the owner's (t, index) word in `share_best` with one
+// 64-bit minimum: smaller t wins, equal t goes to the smaller index (numpy.argmin), and the owner's word starts at
+// (best.t, 0) so that an equal t of this group never replaces a hit of an earlier group or drain (strict <,
+// main.py:144), at (best.t, all ones) if the hit so far is a later group's.  What is left of the list moves to its
+// front; the last, partial round comes after the last entries.
+enum { SPHERE_SHARE_ITEMS = 128 };     // 63 items left over + 64 of one more entry per lane
+__device__ __forceinline__ void sphere_round(SceneArg S, LaneQueue& q, int first, int items, const Ray& r, float t_min,
+                                             float sentinel) {
+    const unsigned lane = threadIdx.x & 63u;
+    const bool have = (int)lane < items;
+    const unsigned item = have ? q.share_list[lane] : 0u;
+    const int owner4 = (int)(item >> 24) * 4;
+    Ray borrowed;
+    borrowed.ox = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.ox)));
+    borrowed.oy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oy)));
+    borrowed.oz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.oz)));
+    borrowed.dx = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dx)));
+    borrowed.dy = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dy)));
+    borrowed.dz = __int_as_float(__builtin_amdgcn_ds_bpermute(owner4, __float_as_int(r.dz)));
+    if (have) {
+        const int prim = first + (int)(item & 0xffffffu);
+        const f32x4 s = S.sph[prim];
+        float h;
+        const float disc = sphere_discriminant(borrowed, s.x, s.y, s.z, s.w, h);
+        const float t = sphere_root(h, disc, t_min, sentinel);
+        // (t == sentinel: both roots before t_min; it can replace nothing)
+        if (disc > 0.00001f && t < sentinel)
+            atomicMin(&q.share_best[item >> 24],
+                      ((unsigned long long)ordered_bits(t) << 32) | (unsigned long long)(unsigned)prim);
+    }
+}
 __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, int first, const Ray& r,
                                               float t_min, float sentinel, Closest& best) {
     WRT_DRAIN_BEGIN(q);
@@ -542,15 +585,31 @@ __device__ __forceinline__ void drain_spheres(SceneArg S, LaneQueue& q, int g, i
         q.count_trips += longest; q.count_items += sum; q.count_longest += longest; q.count_rounds += (sum + 63) / 64;
     }
 #endif
-    for (int k = 0; __ballot(k < q.n) != 0ull; ++k) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long start = ((unsigned long long)ordered_bits(best.t) << 32) |
+                                     (best.group > g ? 0xffffffffull : 0ull);
+    q.share_best[lane] = start;
+    int listed = 0;
+    for (int k = 0;; ++k) {
+        const unsigned long long writers = __ballot(k < q.n);
+        if (writers == 0ull) break;
         if (k < q.n) {
-            const int prim = first + (int)q.slot[k * 64];
-            const f32x4 s = S.sph[prim];
-            float h;
-            const float disc = sphere_discriminant(r, s.x, s.y, s.z, s.w, h);
-            const float t = sphere_root(h, disc, t_min, sentinel);
-            if (disc > 0.00001f && closer(t, g, best)) { best.t = t; best.group = g; best.prim = prim; }
+            const unsigned at = __builtin_amdgcn_mbcnt_hi((unsigned)(writers >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)writers, (unsigned)listed));
+            q.share_list[at] = (lane << 24) | q.slot[k * 64];
         }
+        listed += __popcll(writers);
+        if (listed >= 64) {
+            sphere_round(S, q, first, 64, r, t_min, sentinel);
+            listed -= 64;
+            const unsigned kept = (int)lane < listed ? q.share_list[64 + lane] : 0u;
+            q.share_list[lane] = kept;
+        }
+    }
+    if (listed > 0) sphere_round(S, q, first, listed, r, t_min, sentinel);
+    const unsigned long long won = q.share_best[lane];
+    if (won != start) {
+        best.t = from_ordered_bits((unsigned)(won >> 32)); best.group = g; best.prim = (int)(unsigned)won;
     }
     q.n = 0;
     q.noted = 0;
@@ -858,16 +917,7 @@ __device__ __forceinline__ f32x2 sphere_reject2(const SphereReject& r, const Bou
     return __builtin_elementwise_fma(-Q, E, -r.W);                        // sign set: the line comes near enough
 }
 
-// triangle_group.py:302-399 for the triangles each lane noted, lowest index first
-// float -> unsigned with the same order (and back)
-__device__ __forceinline__ unsigned ordered_bits(float t) {
-    const unsigned b = __float_as_uint(t);
-    return b ^ ((b >> 31) != 0u ? 0xffffffffu : 0x80000000u);
-}
-__device__ __forceinline__ float from_ordered_bits(unsigned o) {
-    return __uint_as_float(o ^ ((o >> 31) != 0u ? 0x80000000u : 0xffffffffu));
-}
-
+// triangle_group.py:302-399 for the triangles each lane noted
 // The lanes' lists differ a lot in length (a ray skimming the mesh passes through dozens of
 // bounding spheres, most pass through a few), so the wave pools them: the lanes write the
 // triangles of all entries into one list, then take 64 items at a time, each borrowing the owner's
