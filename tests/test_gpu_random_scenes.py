@@ -246,3 +246,54 @@ def test_ties_between_large_groups(n_copies, n_per_group):
     assert np.array_equal(got["path_colours"], want["path_colours"])
     assert np.array_equal(got["segments"], want["segments"])
     assert np.array_equal(got["counts"], want["counts"])
+
+
+def doubled_scene(n_per_group, seed, interleave):
+    """Every sphere and every triangle twice inside its group, the copy with another material (spheres) or with
+    other vertex normals and texture coordinates (triangles): every hit is a tie inside a group, which the lower
+    index must win (numpy.argmin), however the wavefront's pooled lists order the candidates."""
+    rng = np.random.default_rng(seed)
+    base = layered_scene(1, n_per_group, seed)
+    spheres = base["groups"][1]
+    n = n_per_group
+    order = np.arange(2 * n).reshape(2, n).T.reshape(-1) if interleave else np.arange(2 * n)
+    materials = dict(base["materials"])
+    materials[2] = dict(kind="metal", colour=np.array([0.9, 0.6, 0.2], np.single), fuzziness=0.0)
+    materials[3] = dict(kind="diffuse", colour=np.array([0.2, 0.8, 0.3], np.single))
+    sph = dict(type="spheres", centres=np.concatenate([spheres["centres"]] * 2)[order],
+               radii=np.concatenate([spheres["radii"]] * 2)[order],
+               materials=np.concatenate([np.full(n, 1, np.ubyte), np.full(n, 2, np.ubyte)])[order])
+    p0 = (rng.uniform(-2, 2, (n, 3)) * np.array([1, 0.4, 1]) + np.array([0, 1.2, 0])).astype(np.single)
+    A = rng.uniform(-0.8, 0.8, (n, 3)).astype(np.single)
+    B = rng.uniform(-0.8, 0.8, (n, 3)).astype(np.single)
+    nrm = np.cross(A, B)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1)[:, None]).astype(np.single)
+    tilted = nrm + np.array([0.3, 0.2, -0.1], np.single)
+    tilted = (tilted / np.linalg.norm(tilted, axis=1)[:, None]).astype(np.single)
+    two = lambda a, b: np.concatenate([a, b])[order]
+    zero, one = np.zeros((n, 2), np.single), np.ones((n, 2), np.single)
+    pts = np.concatenate([p0, p0 + A, p0 + B])
+    bc = np.mean(pts, axis=0).astype(np.single)
+    br = np.single(np.max(np.linalg.norm(pts - bc, axis=1)) * 1.01)
+    tri = dict(type="triangles", pt0=two(p0, p0), A=two(A, A), B=two(B, B), n0=two(nrm, tilted), n1=two(nrm, tilted),
+               n2=two(nrm, tilted), uv0=two(zero, one), uv1=two(zero, one), uv2=two(zero, one), material_id=3,
+               bounds_centre=bc, bounds_radius=br)
+    return dict(camera=base["camera"], groups=[base["groups"][0], sph, tri], materials=materials, sky=base["sky"])
+
+
+@pytest.mark.parametrize("n_per_group,interleave", [(12, False), (12, True), (150, False), (150, True)])
+def test_ties_inside_a_group(n_per_group, interleave):
+    from weekend_raytracer import main
+    scene = doubled_scene(n_per_group, 5 + n_per_group, interleave)
+    w, h, s, b = 64, 40, 2, 6
+    want = numpy_path.render(scene, w, h, s, b, seed=78)
+    objs = (Flat(scene["camera"]), [Flat(g) for g in scene["groups"]],
+            {i: Flat(m) for i, m in scene["materials"].items()})
+    import torch
+    for hierarchy in (0, 16):
+        frame = main.Frame(objs, hierarchy=hierarchy)
+        paths = torch.full((w * h * s, 4), -7.0, dtype=torch.float32, device="cuda")
+        frame.accumulate(w, h, 0, s, b, 78, paths=paths)
+        got = paths.cpu().numpy()
+        frame.ctx.close()
+        assert np.array_equal(got[:, :3], want["path_colours"]), hierarchy
