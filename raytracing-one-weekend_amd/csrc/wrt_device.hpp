@@ -460,9 +460,10 @@ __device__ __forceinline__ float sphere_bound_setup(const Ray& r, bool active, f
 // lane but common for some lane of 64, and the exact evaluation (IEEE square
 // root or division, compares) costs a wavefront more than the arithmetic of
 // the step itself.  Each lane instead notes the primitives it has to look at
-// in a short queue in LDS, in index order, and the wavefront works the queues
-// off together afterwards, each lane fetching its own primitives: a few
-// trips per group instead of one per candidate.
+// in a short queue in LDS, and the wavefront works the queues off together
+// afterwards, the lanes sharing the noted pairs out among themselves
+// (drain_spheres, drain_triangle_blocks): a few rounds per group instead of
+// one per candidate.
 #ifndef WRT_QUEUE_SLOTS
 #define WRT_QUEUE_SLOTS 12
 #endif
