@@ -202,6 +202,7 @@ def launch_ranks(n_ranks, argv, job_timeout=540.0, log_dir=None):
     for rank in range(n_ranks):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
                    LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL between processes needs here
         log_path = os.path.join(log_dir, f"bench_rank{rank}.err")
         log = open(log_path, "wb")
         logs.append((log_path, log))
@@ -313,6 +314,7 @@ def main():
         # a plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], job_timeout=args.job_timeout))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (before anything initialises the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
