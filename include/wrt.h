@@ -57,6 +57,7 @@ enum {
     WRT_MAX_TEXTURES = 16,
     WRT_MAX_GROUPS = 4096,
     WRT_MAX_GROUP_TRIANGLES = 1 << 20,   /* per triangle group (split larger meshes into several groups) */
+    WRT_MAX_GROUP_SPHERES = 1 << 24,     /* per sphere group (likewise) */
     WRT_MAX_SCENE_PRIMITIVES = 1 << 26,  /* spheres, and triangles, over all groups of a scene */
     WRT_STATIC_MAX_PIXELS = 4 << 20      /* width * height limit of wrt_render_static (64 MiB of path records) */
 };

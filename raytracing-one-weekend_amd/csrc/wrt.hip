@@ -1048,6 +1048,10 @@ static int new_group(wrt_ctx* ctx, const GroupRec& g, int* group_id) {
 // vectors.  (Apart from the entry points so that a host-only driver can feed them without a GPU:
 // tests/native/check_host.hip runs them under the address and undefined-behaviour sanitizers.)
 static int sphere_group_fits(wrt_ctx* ctx, int count) {
+    // (the wavefront's pooled work items carry a sphere's index inside its group in 24 bits)
+    if (count > WRT_MAX_GROUP_SPHERES)
+        return fail(ctx, WRT_E_LIMIT, "wrt_add_sphere_group: more than WRT_MAX_GROUP_SPHERES (16777216) spheres in one "
+                                      "group: split the group");
     if (ctx->h_sph.size() + (size_t)count > (size_t)WRT_MAX_SCENE_PRIMITIVES)
         return fail(ctx, WRT_E_LIMIT, "wrt_add_sphere_group: more than WRT_MAX_SCENE_PRIMITIVES spheres in the scene");
     return WRT_OK;

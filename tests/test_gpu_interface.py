@@ -222,6 +222,8 @@ def test_stage_calls_need_a_committed_scene():
     p = big.ctypes.data_as(ctypes.c_void_p)
     rc = ctx.lib.wrt_add_triangle_group(ctx.handle, p, p, p, p, p, p, p, p, p, (1 << 20) + 1, 0, p, 1.0, None)
     assert rc == -4 and b"WRT_MAX_GROUP_TRIANGLES" in ctx.lib.wrt_last_error(ctx.handle)
+    rc = ctx.lib.wrt_add_sphere_group(ctx.handle, p, p, p, (1 << 24) + 1, None)
+    assert rc == -4 and b"WRT_MAX_GROUP_SPHERES" in ctx.lib.wrt_last_error(ctx.handle)
     torch.cuda.synchronize()
     ctx.close()
 
